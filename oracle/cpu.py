@@ -1,0 +1,150 @@
+"""ctypes front-end of the CPU checker libraries -- TEST INFRASTRUCTURE ONLY.
+
+Functions follow the reference's driver loops:
+  init_mt      fdtd1.cu:21-31        run("star", M)   fdtdN.cu:40-52 (golden) / :61-64 (device order)
+  init_jacobi  jacobi.cu:412-417     run("spc13")     fdtdspc.cu:40-55 / :64-73
+                                     run("jacobi7")   jacobi.cu:474-490 / :31-38
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORDER_GOLDEN, ORDER_CHAIN = 0, 1
+KINDS = {"star": 0, "spc13": 1, "jacobi7": 2}
+
+# coefficient sets of the shipped drivers
+STAR_COEF = np.array([0.01, 0.02, 0.03, 0.04, 0.05, 0.06, 0.07], dtype=np.float32)  # fdtd1.cu:46-49
+SPC13_COEF = np.array([0.01, 0.02, 0.03, 0.04, 0.05, 0.06, 0.07, 0.02, 0.03, 0.04, 0.05, 0.06, 0.07],
+                      dtype=np.float32)  # fdtdspc.cu:66-72
+JACOBI_COEF = np.array([0.01, 0.02, 0.03, 0.04, 0.05, 0.06, 0.07], dtype=np.float32)  # jacobi.cu:15-21
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+
+
+def _p(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_f32p)
+
+
+def build():
+    """(Re)build liboracle.so and, where the reference is present, oracle/_ref."""
+    subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = ctypes.CDLL(path)
+        sz = ctypes.c_size_t
+        L.oracle_init_mt.argtypes = [_f32p, _f32p, _f32p, ctypes.c_int, sz, sz, sz, sz]
+        L.oracle_init_jacobi.argtypes = [_f32p, sz, sz, sz]
+        L.oracle_star_step.argtypes = [_f32p, _f32p, sz, sz, sz, ctypes.c_int, _f32p, ctypes.c_int, sz, sz]
+        L.oracle_spc13_step.argtypes = [_f32p, _f32p, sz, sz, sz, _f32p, ctypes.c_int, sz, sz]
+        L.oracle_jacobi7_step.argtypes = [_f32p, _f32p, sz, sz, sz, _f32p, ctypes.c_int, sz, sz]
+        L.oracle_run.argtypes = [ctypes.c_int, _f32p, _f32p, sz, sz, sz, ctypes.c_int, _f32p, ctypes.c_int,
+                                 ctypes.c_int]
+        for f in (L.oracle_init_mt, L.oracle_init_jacobi, L.oracle_star_step, L.oracle_spc13_step,
+                  L.oracle_jacobi7_step, L.oracle_run):
+            f.restype = None
+        _lib = L
+    return _lib
+
+
+def init_mt(nz, ny, nx, z_begin=0, nfields=2):
+    """Initial fields of fdtdN/fdtdspc (2 fields) or main.cu (3 fields) for planes [z_begin, z_begin+nz)."""
+    p0 = np.empty((nz, ny, nx), np.float32)
+    p1 = np.empty((nz, ny, nx), np.float32)
+    f2 = np.empty((nz, ny, nx), np.float32) if nfields == 3 else None
+    lib().oracle_init_mt(_p(p0), _p(p1), _p(f2) if f2 is not None else None, nfields, z_begin, nz, ny, nx)
+    return (p0, p1) if nfields == 2 else (p0, p1, f2)
+
+
+def init_jacobi(nz, ny, nx):
+    a = np.empty((nz, ny, nx), np.float32)
+    lib().oracle_init_jacobi(_p(a), nz, ny, nx)
+    return a
+
+
+def default_coef(kind):
+    return {"star": STAR_COEF, "spc13": SPC13_COEF, "jacobi7": JACOBI_COEF}[kind]
+
+
+def step(kind, out, inp, M=1, coef=None, order=ORDER_CHAIN, z_lo=None, z_hi=None):
+    """One sweep out = f(inp) over local planes [z_lo, z_hi) (default: the whole interior)."""
+    nz, ny, nx = inp.shape
+    coef = np.ascontiguousarray(default_coef(kind) if coef is None else coef, np.float32)
+    h = M if kind == "star" else 1
+    z_lo = h if z_lo is None else z_lo
+    z_hi = nz - h if z_hi is None else z_hi
+    L = lib()
+    if kind == "star":
+        L.oracle_star_step(_p(out), _p(inp), nz, ny, nx, M, _p(coef), order, z_lo, z_hi)
+    elif kind == "spc13":
+        L.oracle_spc13_step(_p(out), _p(inp), nz, ny, nx, _p(coef), order, z_lo, z_hi)
+    else:
+        L.oracle_jacobi7_step(_p(out), _p(inp), nz, ny, nx, _p(coef), order, z_lo, z_hi)
+
+
+def run(kind, a, b, steps, M=1, coef=None, order=ORDER_CHAIN):
+    """`steps` ping-pong steps in place: step 0 writes a = f(b), then the roles swap."""
+    nz, ny, nx = a.shape
+    coef = np.ascontiguousarray(default_coef(kind) if coef is None else coef, np.float32)
+    lib().oracle_run(KINDS[kind], _p(a), _p(b), nz, ny, nx, M, _p(coef), order, steps)
+
+
+# ----------------------------------------------------------------------------------------------
+# the reference's own loops (oracle/_ref), when built
+# ----------------------------------------------------------------------------------------------
+_ref = None
+
+
+def ref_available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libfdtd_ref_strict.so"))
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        L = ctypes.CDLL(os.path.join(_HERE, "_ref", "libfdtd_ref_strict.so"))
+        sz = ctypes.c_size_t
+        i64 = ctypes.c_int64
+        L.ref_init_mt.argtypes = [_f32p, _f32p, sz, sz, sz]
+        L.ref_init_mt3.argtypes = [_f32p, _f32p, _f32p, _f32p, sz, sz, sz]
+        L.ref_star_step.argtypes = [ctypes.c_int, _f32p, _f32p, sz, sz, sz]
+        L.ref_spc13_step.argtypes = [_f32p, _f32p, sz, sz, sz]
+        L.ref_init_jacobi.argtypes = [_f32p, _f32p, i64, i64, i64]
+        L.ref_jacobi_step.argtypes = [_f32p, _f32p, i64, i64, i64]
+        L.ref_main_step.argtypes = [_f32p, _f32p, _f32p, _f32p, ctypes.POINTER(ctypes.c_size_t), sz, sz, sz, sz]
+        L.ref_run.argtypes = [ctypes.c_int, ctypes.c_int, _f32p, _f32p, sz, sz, sz, ctypes.c_int]
+        L.ref_run.restype = ctypes.c_int
+        _ref = L
+    return _ref
+
+
+def ref_init_mt(nz, ny, nx):
+    p0 = np.empty((nz, ny, nx), np.float32)
+    p1 = np.empty((nz, ny, nx), np.float32)
+    ref().ref_init_mt(_p(p0), _p(p1), nz, ny, nx)
+    return p0, p1
+
+
+def ref_init_jacobi(nz, ny, nx):
+    a = np.empty((nz, ny, nx), np.float32)
+    b = np.empty((nz, ny, nx), np.float32)
+    ref().ref_init_jacobi(_p(a), _p(b), nz, ny, nx)
+    return a, b
+
+
+def ref_run(kind, a, b, steps, M=1):
+    nz, ny, nx = a.shape
+    rc = ref().ref_run(KINDS[kind], M, _p(a), _p(b), nz, ny, nx, steps)
+    assert rc == 0

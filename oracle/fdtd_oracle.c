@@ -1,0 +1,249 @@
+/*
+ * fdtd_oracle.c -- CPU restatement of the reference's field-update sweeps.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (fdtd_amd/, include/)
+ * may call, link or load this file; it is the checker for the HIP kernels and
+ * the "port" CPU baseline of bench.py.
+ *
+ * Parity status: PINNED.  Every *_golden function below is checked bit-for-bit
+ * (tests/test_oracle_vs_ref.py) against the reference's own CPU golden loops
+ * compiled from /root/reference by oracle/build_ref.sh with strict IEEE flags
+ * (-O2 -ffp-contract=off), and against the committed fixtures in tests/golden/
+ * that were produced by those compiled loops.
+ *
+ * Two summation orders exist for every stencil because the reference itself has
+ * two implementations of each update:
+ *   ORDER_GOLDEN  the host loop: centre + parenthesised (+r,-r) pairs, plain
+ *                 IEEE mul/add          (fdtd1.cu:46-49 ... fdtd8.cu:46-70,
+ *                                        fdtdspc.cu:46-52, jacobi.cu:478-485)
+ *   ORDER_CHAIN   the device lambda: one flat left-to-right sum, every "+ c*v"
+ *                 contracted to an FMA as nvcc's default -fmad=true does
+ *                                       (fdtd1.cu:61-64 ... fdtd8.cu:82-93,
+ *                                        fdtdspc.cu:64-73, jacobi.cu:31-38)
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp -shared).
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#define ORDER_GOLDEN 0
+#define ORDER_CHAIN 1
+
+#define IDX(z, y, x, ny, nx) (((size_t)(z) * (ny) + (y)) * (nx) + (x))
+
+/* ------------------------------------------------------------------------- */
+/* std::mt19937_64 (ISO C++ [rand.predef]): the generator the reference seeds  */
+/* per z-plane with 19950918+z (fdtd1.cu:24).                                  */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t s[312];
+    int i;
+} mt64_t;
+
+static void mt64_seed(mt64_t *g, uint64_t seed)
+{
+    g->s[0] = seed;
+    for (int k = 1; k < 312; k++)
+        g->s[k] = 6364136223846793005ULL * (g->s[k - 1] ^ (g->s[k - 1] >> 62)) + (uint64_t)k;
+    g->i = 312;
+}
+
+static uint64_t mt64_next(mt64_t *g)
+{
+    if (g->i >= 312) {
+        const uint64_t UM = 0xFFFFFFFF80000000ULL, LM = 0x7FFFFFFFULL, A = 0xB5026F5AA96619E9ULL;
+        for (int k = 0; k < 312; k++) {
+            uint64_t x = (g->s[k] & UM) | (g->s[(k + 1) % 312] & LM);
+            g->s[k] = g->s[(k + 156) % 312] ^ (x >> 1) ^ ((x & 1) ? A : 0);
+        }
+        g->i = 0;
+    }
+    uint64_t x = g->s[g->i++];
+    x ^= (x >> 29) & 0x5555555555555555ULL;
+    x ^= (x << 17) & 0x71D67FFFEDA60000ULL;
+    x ^= (x << 37) & 0xFFF7EEE000000000ULL;
+    x ^= x >> 43;
+    return x;
+}
+
+/* float(rand())/rand.max(): both operands become float, max() == 2^64-1 rounds to 2^64. */
+static inline float mt64_unit(mt64_t *g)
+{
+    return (float)mt64_next(g) / (float)UINT64_MAX;
+}
+
+/*
+ * Initial fields of the fdtdN / fdtdspc drivers (fdtd1.cu:21-31): per global plane z a
+ * generator seeded 19950918+z draws p0 then p1 for every cell in (y,x) order.
+ * Fills planes [z_begin, z_begin+nz_local) of the global grid into local arrays.
+ * nfields = 2 (fdtdN) or 3 (main.cu:27-35 draws vel as a third value); f2 may be NULL.
+ */
+void oracle_init_mt(float *p0, float *p1, float *f2, int nfields, size_t z_begin, size_t nz_local,
+                    size_t ny, size_t nx)
+{
+#pragma omp parallel for
+    for (size_t z = 0; z < nz_local; z++) {
+        mt64_t g;
+        mt64_seed(&g, 19950918ULL + z_begin + z);
+        for (size_t y = 0; y < ny; y++)
+            for (size_t x = 0; x < nx; x++) {
+                size_t a = IDX(z, y, x, ny, nx);
+                p0[a] = mt64_unit(&g);
+                p1[a] = mt64_unit(&g);
+                if (nfields == 3) {
+                    float v = mt64_unit(&g);
+                    if (f2) f2[a] = v;
+                }
+            }
+    }
+}
+
+/* Initial field of jacobi.cu:412-417: i - j + 1.0/(k+1) evaluated in double, stored as float. */
+void oracle_init_jacobi(float *a, size_t nz, size_t ny, size_t nx)
+{
+#pragma omp parallel for
+    for (size_t k = 0; k < nz; k++)
+        for (size_t j = 0; j < ny; j++)
+            for (size_t i = 0; i < nx; i++)
+                a[IDX(k, j, i, ny, nx)] = (float)((double)((int64_t)i - (int64_t)j) + 1.0 / (double)(k + 1));
+}
+
+/* ------------------------------------------------------------------------- */
+/* star-M: coef = {centre, x+, x-, y+, y-, z+, z-}, the same six for every r.  */
+/* Interior [M, n-M) per axis; the shell of `out` is not touched.              */
+/* The sweep covers planes [z_lo, z_hi) of a local array whose planes are      */
+/* addressed 0..nzl-1 (callers pass z_lo>=M, z_hi<=nzl-M).                      */
+/* ------------------------------------------------------------------------- */
+void oracle_star_step(float *out, const float *in, size_t nzl, size_t ny, size_t nx, int M,
+                      const float *coef, int order, size_t z_lo, size_t z_hi)
+{
+    (void)nzl;
+    const float c0 = coef[0], cxp = coef[1], cxm = coef[2], cyp = coef[3], cym = coef[4],
+                czp = coef[5], czm = coef[6];
+    const size_t sy = nx, sz = ny * nx;
+#pragma omp parallel for
+    for (size_t z = z_lo; z < z_hi; z++)
+        for (size_t y = (size_t)M; y < ny - (size_t)M; y++)
+            for (size_t x = (size_t)M; x < nx - (size_t)M; x++) {
+                const float *p = in + IDX(z, y, x, ny, nx);
+                float acc = c0 * p[0];
+                if (order == ORDER_GOLDEN) {
+                    for (int r = 1; r <= M; r++) {
+                        acc = acc + (cxp * p[r] + cxm * p[-r]);
+                        acc = acc + (cyp * p[(size_t)r * sy] + cym * p[-(ptrdiff_t)((size_t)r * sy)]);
+                        acc = acc + (czp * p[(size_t)r * sz] + czm * p[-(ptrdiff_t)((size_t)r * sz)]);
+                    }
+                } else {
+                    for (int r = 1; r <= M; r++) {
+                        acc = fmaf(cxp, p[r], acc);
+                        acc = fmaf(cxm, p[-r], acc);
+                        acc = fmaf(cyp, p[(size_t)r * sy], acc);
+                        acc = fmaf(cym, p[-(ptrdiff_t)((size_t)r * sy)], acc);
+                        acc = fmaf(czp, p[(size_t)r * sz], acc);
+                        acc = fmaf(czm, p[-(ptrdiff_t)((size_t)r * sz)], acc);
+                    }
+                }
+                out[IDX(z, y, x, ny, nx)] = acc;
+            }
+}
+
+/* ------------------------------------------------------------------------- */
+/* spc-13 (fdtdspc.cu:46-52 host, :66-72 device).  coef[13] in lambda order:   */
+/*  0 C | 1 x+1 | 2 x-1 | 3 y+1 | 4 y-1 | 5 z+1 | 6 z-1 | 7 (y+1,x+1) |         */
+/*  8 (y-1,x-1) | 9 (z+1,y+1) | 10 (z-1,y-1) | 11 (z+1,y+1,x+1) | 12 (z-1,y-1,x-1) */
+/* ------------------------------------------------------------------------- */
+void oracle_spc13_step(float *out, const float *in, size_t nzl, size_t ny, size_t nx,
+                       const float *c, int order, size_t z_lo, size_t z_hi)
+{
+    (void)nzl;
+    const ptrdiff_t sy = (ptrdiff_t)nx, sz = (ptrdiff_t)(ny * nx);
+#pragma omp parallel for
+    for (size_t z = z_lo; z < z_hi; z++)
+        for (size_t y = 1; y < ny - 1; y++)
+            for (size_t x = 1; x < nx - 1; x++) {
+                const float *p = in + IDX(z, y, x, ny, nx);
+                float acc;
+                if (order == ORDER_GOLDEN) {
+                    acc = c[0] * p[0];
+                    acc = acc + (c[1] * p[1] + c[2] * p[-1]);
+                    acc = acc + (c[3] * p[sy] + c[4] * p[-sy]);
+                    acc = acc + (c[5] * p[sz] + c[6] * p[-sz]);
+                    acc = acc + (c[7] * p[sy + 1] + c[8] * p[-sy - 1]);
+                    acc = acc + (c[9] * p[sz + sy] + c[10] * p[-sz - sy]);
+                    acc = acc + (c[11] * p[sz + sy + 1] + c[12] * p[-sz - sy - 1]);
+                } else {
+                    acc = c[0] * p[0];
+                    acc = fmaf(c[1], p[1], acc);
+                    acc = fmaf(c[2], p[-1], acc);
+                    acc = fmaf(c[3], p[sy], acc);
+                    acc = fmaf(c[4], p[-sy], acc);
+                    acc = fmaf(c[5], p[sz], acc);
+                    acc = fmaf(c[6], p[-sz], acc);
+                    acc = fmaf(c[7], p[sy + 1], acc);
+                    acc = fmaf(c[8], p[-sy - 1], acc);
+                    acc = fmaf(c[9], p[sz + sy], acc);
+                    acc = fmaf(c[10], p[-sz - sy], acc);
+                    acc = fmaf(c[11], p[sz + sy + 1], acc);
+                    acc = fmaf(c[12], p[-sz - sy - 1], acc);
+                }
+                out[IDX(z, y, x, ny, nx)] = acc;
+            }
+}
+
+/* ------------------------------------------------------------------------- */
+/* jacobi-7 (jacobi.cu:31-38 device, :478-485 host check loop).                */
+/* coef = {cc, ce(x+1), cw(x-1), cs(y+1), cn(y-1), ct(z+1), cb(z-1)};          */
+/* evaluation order ce*E + cw*W + cs*S + cn*N + ct*T + cb*B + cc*C.            */
+/* Boundary cells are never written (both arrays start identical).            */
+/* ------------------------------------------------------------------------- */
+void oracle_jacobi7_step(float *out, const float *in, size_t nzl, size_t ny, size_t nx,
+                         const float *coef, int order, size_t z_lo, size_t z_hi)
+{
+    (void)nzl;
+    const float cc = coef[0], ce = coef[1], cw = coef[2], cs = coef[3], cn = coef[4], ct = coef[5],
+                cb = coef[6];
+    const ptrdiff_t sy = (ptrdiff_t)nx, sz = (ptrdiff_t)(ny * nx);
+#pragma omp parallel for
+    for (size_t z = z_lo; z < z_hi; z++)
+        for (size_t y = 1; y < ny - 1; y++)
+            for (size_t x = 1; x < nx - 1; x++) {
+                const float *p = in + IDX(z, y, x, ny, nx);
+                float acc;
+                if (order == ORDER_GOLDEN) {
+                    acc = ce * p[1] + cw * p[-1] + cs * p[sy] + cn * p[-sy] + ct * p[sz] + cb * p[-sz] +
+                          cc * p[0];
+                } else {
+                    acc = ce * p[1];
+                    acc = fmaf(cw, p[-1], acc);
+                    acc = fmaf(cs, p[sy], acc);
+                    acc = fmaf(cn, p[-sy], acc);
+                    acc = fmaf(ct, p[sz], acc);
+                    acc = fmaf(cb, p[-sz], acc);
+                    acc = fmaf(cc, p[0], acc);
+                }
+                out[IDX(z, y, x, ny, nx)] = acc;
+            }
+}
+
+/* kind: 0 star (M, coef[7]) | 1 spc13 (coef[13]) | 2 jacobi7 (coef[7]).       */
+/* Runs `steps` ping-pong steps exactly as the drivers do (fdtd1.cu:40-52):    */
+/* step t writes a = f(b) then swaps the roles.  On return the arrays hold     */
+/* what the reference holds: after an odd count `a` is the newest field.       */
+void oracle_run(int kind, float *a, float *b, size_t nz, size_t ny, size_t nx, int M, const float *coef,
+                int order, int steps)
+{
+    float *out = a, *in = b;
+    for (int t = 0; t < steps; t++) {
+        if (kind == 0)
+            oracle_star_step(out, in, nz, ny, nx, M, coef, order, (size_t)M, nz - (size_t)M);
+        else if (kind == 1)
+            oracle_spc13_step(out, in, nz, ny, nx, coef, order, 1, nz - 1);
+        else
+            oracle_jacobi7_step(out, in, nz, ny, nx, coef, order, 1, nz - 1);
+        float *t2 = out;
+        out = in;
+        in = t2;
+    }
+}
