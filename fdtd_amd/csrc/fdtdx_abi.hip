@@ -1,0 +1,538 @@
+// fdtdx_abi.hip -- host side of the C ABI declared in include/fdtdx.h.
+//
+// Mirrors the host runtime of the reference's Stencil<> class (stencil.h:357-842): named device
+// buffer pool, z-slab decomposition, padded layout, padded transfers, sweep dispatch.  Process
+// to process communication is NOT in here (the reference calls MPI at stencil.h:639-656): this
+// library exposes the contiguous ghost/boundary plane regions (fdtdx_halo_region) and the
+// caller moves them with RCCL send/recv (fdtd_amd/slab.py) while the interior sweep runs.
+#include "../../include/fdtdx.h"
+#include "sweep_common.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace fdtdx {
+
+// ---- variant registries ----------------------------------------------------------------------
+static std::vector<VariantInfo> &vreg()
+{
+    static std::vector<VariantInfo> v;
+    return v;
+}
+static std::vector<SpcVariantInfo> &sreg()
+{
+    static std::vector<SpcVariantInfo> v;
+    return v;
+}
+int num_variants() { return (int)vreg().size(); }
+const VariantInfo *variant(int i) { return &vreg()[i]; }
+void register_variant(const VariantInfo &v) { vreg().push_back(v); }
+int num_spc_variants() { return (int)sreg().size(); }
+const SpcVariantInfo *spc_variant(int i) { return &sreg()[i]; }
+void register_spc_variant(const SpcVariantInfo &v) { sreg().push_back(v); }
+
+}  // namespace fdtdx
+
+using namespace fdtdx;
+
+// ---- error reporting -----------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(FDTDX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct Cube {
+    float *ptr = nullptr;
+    bool owned = false;
+};
+
+struct fdtdx_ctx {
+    fdtdx_config cfg;
+    fdtdx_geometry g;
+    int device = 0;
+    std::map<std::string, Cube> pool;  // memoryPool of stencil.h:361
+    int64_t opt_zchunks = 0;           // 0 = auto
+    int64_t opt_variant = -1;          // -1 = auto
+    char last_launch[256] = "";
+};
+
+extern "C" const char *fdtdx_last_error(void) { return g_err; }
+
+// ---- decomposition (stencil.h:398-412) ---------------------------------------------------------
+extern "C" int fdtdx_decompose(const fdtdx_config *cfg, fdtdx_geometry *out)
+{
+    if (!cfg || !out) return fail(FDTDX_ERR_INVALID, "null argument");
+    const uint64_t M = cfg->M, np = cfg->nprocs, r = cfg->rank;
+    if (M < 1 || M > 8) return fail(FDTDX_ERR_INVALID, "M=%u outside 1..8 (stencil.h:387)", cfg->M);
+    if (np < 1 || r >= np) return fail(FDTDX_ERR_INVALID, "rank %u / nprocs %u", cfg->rank, cfg->nprocs);
+    if (cfg->Z < 2 * M + 1 || cfg->Y < 2 * M + 1 || cfg->X < 2 * M + 1)
+        return fail(FDTDX_ERR_INVALID, "grid %llux%llux%llu smaller than 2M+1 (stencil.h:387)",
+                    (unsigned long long)cfg->Z, (unsigned long long)cfg->Y, (unsigned long long)cfg->X);
+    uint64_t px = cfg->pitch_x ? cfg->pitch_x : (cfg->X / 32 + 1) * 32;
+    if (px % 32 != 0 || px < cfg->X) return fail(FDTDX_ERR_INVALID, "pitch_x %llu must be a multiple of 32 >= X", (unsigned long long)px);
+    if (cfg->Y * px > 0x7fffffffull) return fail(FDTDX_ERR_UNSUPPORTED, "plane of %llu floats exceeds 2^31", (unsigned long long)(cfg->Y * px));
+    uint64_t off = 0, size = 0;
+    for (uint64_t i = 0; i < np; i++) {
+        uint64_t s = cfg->Z / np + ((cfg->Z % np) > i ? 1 : 0);  // mpiSize[i]
+        if (s <= 2 * M) return fail(FDTDX_ERR_INVALID, "slab %llu has %llu planes, needs > 2M (stencil.h:403)", (unsigned long long)i, (unsigned long long)s);
+        if (i == r) {
+            size = s;
+            break;
+        }
+        off += s;
+    }
+    fdtdx_geometry g;
+    g.pitch_x = px;
+    g.plane = cfg->Y * px;
+    g.owned_begin = off;
+    g.owned_planes = size;
+    g.ghost_lo = (r == 0) ? 0 : M;
+    g.ghost_hi = (r == np - 1) ? 0 : M;
+    g.local_planes = g.ghost_lo + size + g.ghost_hi;
+    g.first_global = off - g.ghost_lo;
+    g.update_lo = M;
+    g.update_hi = g.local_planes - M;
+    g.cube_elems = g.local_planes * g.plane;
+    *out = g;
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_create(const fdtdx_config *cfg, fdtdx_ctx **out)
+{
+    if (!cfg || !out) return fail(FDTDX_ERR_INVALID, "null argument");
+    fdtdx_geometry g;
+    int rc = fdtdx_decompose(cfg, &g);
+    if (rc) return rc;
+    if (g.local_planes > 0x7fffffffull) return fail(FDTDX_ERR_UNSUPPORTED, "too many planes");
+    int dev = cfg->device;
+    if (dev >= 0)
+        HIP_TRY(hipSetDevice(dev));
+    else
+        HIP_TRY(hipGetDevice(&dev));
+    fdtdx_ctx *c = new (std::nothrow) fdtdx_ctx;
+    if (!c) return fail(FDTDX_ERR_NOMEM, "out of host memory");
+    c->cfg = *cfg;
+    c->g = g;
+    c->device = dev;
+    *out = c;
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_destroy(fdtdx_ctx *ctx)
+{
+    if (!ctx) return FDTDX_OK;
+    int rc = FDTDX_OK;
+    for (auto &kv : ctx->pool)
+        if (kv.second.owned && kv.second.ptr && hipFree(kv.second.ptr) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(%s) failed", kv.first.c_str());
+    delete ctx;
+    return rc;
+}
+
+extern "C" int fdtdx_get_geometry(const fdtdx_ctx *ctx, fdtdx_geometry *out)
+{
+    if (!ctx || !out) return fail(FDTDX_ERR_INVALID, "null argument");
+    *out = ctx->g;
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_rank(const fdtdx_ctx *ctx) { return ctx ? (int)ctx->cfg.rank : -1; }
+extern "C" int fdtdx_nprocs(const fdtdx_ctx *ctx) { return ctx ? (int)ctx->cfg.nprocs : -1; }
+
+extern "C" int fdtdx_sync(fdtdx_ctx *ctx)
+{
+    if (!ctx) return fail(FDTDX_ERR_INVALID, "null context");
+    HIP_TRY(hipDeviceSynchronize());
+    return FDTDX_OK;
+}
+
+// ---- pool ------------------------------------------------------------------------------------
+extern "C" int fdtdx_malloc_cube(fdtdx_ctx *ctx, const char *name)
+{
+    if (!ctx || !name) return fail(FDTDX_ERR_INVALID, "null argument");
+    if (ctx->pool.count(name)) return fail(FDTDX_ERR_EXISTS, "cube '%s' already exists (stencil.h:555)", name);
+    float *p = nullptr;
+    size_t bytes = ctx->g.cube_elems * sizeof(float);
+    HIP_TRY(hipMalloc((void **)&p, bytes));
+    hipError_t e = hipMemset(p, 0, bytes);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return fail(FDTDX_ERR_HIP, "hipMemset: %s", hipGetErrorString(e));
+    }
+    Cube c;
+    c.ptr = p;
+    c.owned = true;
+    ctx->pool[name] = c;
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_attach_cube(fdtdx_ctx *ctx, const char *name, void *device_ptr, size_t bytes)
+{
+    if (!ctx || !name || !device_ptr) return fail(FDTDX_ERR_INVALID, "null argument");
+    if (ctx->pool.count(name)) return fail(FDTDX_ERR_EXISTS, "cube '%s' already exists", name);
+    if (bytes < ctx->g.cube_elems * sizeof(float))
+        return fail(FDTDX_ERR_INVALID, "attach '%s': %zu bytes < cube size %zu", name, bytes, (size_t)(ctx->g.cube_elems * sizeof(float)));
+    if (((uintptr_t)device_ptr & 15u) != 0) return fail(FDTDX_ERR_INVALID, "attach '%s': pointer not 16-byte aligned", name);
+    Cube c;
+    c.ptr = (float *)device_ptr;
+    c.owned = false;
+    ctx->pool[name] = c;
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_free(fdtdx_ctx *ctx, const char *name)
+{
+    if (!ctx || !name) return fail(FDTDX_ERR_INVALID, "null argument");
+    auto it = ctx->pool.find(name);
+    if (it == ctx->pool.end()) return fail(FDTDX_ERR_NOTFOUND, "no cube '%s' (stencil.h:470)", name);
+    if (it->second.owned) HIP_TRY(hipFree(it->second.ptr));
+    ctx->pool.erase(it);
+    return FDTDX_OK;
+}
+
+static int find_cube(fdtdx_ctx *ctx, const char *name, float **p)
+{
+    if (!ctx || !name) return fail(FDTDX_ERR_INVALID, "null argument");
+    auto it = ctx->pool.find(name);
+    if (it == ctx->pool.end()) return fail(FDTDX_ERR_NOTFOUND, "no cube '%s' (stencil.h:580)", name);
+    *p = it->second.ptr;
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_get_cube(fdtdx_ctx *ctx, const char *name, float **device_ptr)
+{
+    if (!device_ptr) return fail(FDTDX_ERR_INVALID, "null argument");
+    return find_cube(ctx, name, device_ptr);
+}
+
+// ---- transfers (stencil.h:596-637): pitch conversion done by the copy engine -------------------
+static int copy_planes_h2d(fdtdx_ctx *ctx, float *dev, const float *host, uint64_t nplanes)
+{
+    const fdtdx_geometry &g = ctx->g;
+    const uint64_t X = ctx->cfg.X, Y = ctx->cfg.Y;
+    HIP_TRY(hipMemcpy2D(dev, g.pitch_x * sizeof(float), host, X * sizeof(float), X * sizeof(float), nplanes * Y, hipMemcpyHostToDevice));
+    return FDTDX_OK;
+}
+static int copy_planes_d2h(fdtdx_ctx *ctx, float *host, const float *dev, uint64_t nplanes)
+{
+    const fdtdx_geometry &g = ctx->g;
+    const uint64_t X = ctx->cfg.X, Y = ctx->cfg.Y;
+    HIP_TRY(hipMemcpy2D(host, X * sizeof(float), dev, g.pitch_x * sizeof(float), X * sizeof(float), nplanes * Y, hipMemcpyDeviceToHost));
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_transfer_cube_to_gpu(fdtdx_ctx *ctx, const char *name, const float *host)
+{
+    float *d;
+    int rc = find_cube(ctx, name, &d);
+    if (rc) return rc;
+    if (!host) return fail(FDTDX_ERR_INVALID, "null host pointer");
+    const fdtdx_geometry &g = ctx->g;
+    return copy_planes_h2d(ctx, d, host + g.first_global * ctx->cfg.Y * ctx->cfg.X, g.local_planes);
+}
+
+extern "C" int fdtdx_upload_local(fdtdx_ctx *ctx, const char *name, const float *host_local)
+{
+    float *d;
+    int rc = find_cube(ctx, name, &d);
+    if (rc) return rc;
+    if (!host_local) return fail(FDTDX_ERR_INVALID, "null host pointer");
+    return copy_planes_h2d(ctx, d, host_local, ctx->g.local_planes);
+}
+
+extern "C" int fdtdx_transfer_cube_to_cpu(fdtdx_ctx *ctx, float *host, const char *name)
+{
+    float *d;
+    int rc = find_cube(ctx, name, &d);
+    if (rc) return rc;
+    if (!host) return fail(FDTDX_ERR_INVALID, "null host pointer");
+    const fdtdx_geometry &g = ctx->g;
+    return copy_planes_d2h(ctx, host + g.owned_begin * ctx->cfg.Y * ctx->cfg.X, d + g.ghost_lo * g.plane, g.owned_planes);
+}
+
+extern "C" int fdtdx_download_owned(fdtdx_ctx *ctx, float *host_owned, const char *name)
+{
+    float *d;
+    int rc = find_cube(ctx, name, &d);
+    if (rc) return rc;
+    if (!host_owned) return fail(FDTDX_ERR_INVALID, "null host pointer");
+    const fdtdx_geometry &g = ctx->g;
+    return copy_planes_d2h(ctx, host_owned, d + g.ghost_lo * g.plane, g.owned_planes);
+}
+
+// ---- driver initial conditions -------------------------------------------------------------------
+extern "C" int fdtdx_init_mt(fdtdx_ctx *ctx, const char *name_p0, const char *name_p1)
+{
+    float *d0, *d1;
+    int rc = find_cube(ctx, name_p0, &d0);
+    if (rc) return rc;
+    rc = find_cube(ctx, name_p1, &d1);
+    if (rc) return rc;
+    const fdtdx_geometry &g = ctx->g;
+    const uint64_t X = ctx->cfg.X, Y = ctx->cfg.Y;
+    // stage a bounded number of planes at a time so host memory stays small for big slabs
+    const uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(g.local_planes, (256ull << 20) / (Y * X * sizeof(float)) + 1));
+    std::vector<float> h0(batch * Y * X), h1(batch * Y * X);
+    for (uint64_t zb = 0; zb < g.local_planes; zb += batch) {
+        const uint64_t n = std::min(batch, g.local_planes - zb);
+        // fdtd1.cu:21: the reference parallelises over planes with OpenMP; plain threads here
+        auto fill = [&](uint64_t zi) {
+            // fdtd1.cu:24-30: one generator per global plane, p0 then p1 per cell
+            std::mt19937_64 gen(19950918ull + g.first_global + zb + zi);
+            float *a = h0.data() + zi * Y * X, *b = h1.data() + zi * Y * X;
+            for (uint64_t i = 0; i < Y * X; i++) {
+                a[i] = float(gen()) / float(gen.max());
+                b[i] = float(gen()) / float(gen.max());
+            }
+        };
+        const unsigned nthr = std::max(1u, std::min<unsigned>(16u, std::min<unsigned>((unsigned)n, std::thread::hardware_concurrency())));
+        std::vector<std::thread> pool;
+        for (unsigned w = 0; w < nthr; w++)
+            pool.emplace_back([&, w]() {
+                for (uint64_t zi = w; zi < n; zi += nthr) fill(zi);
+            });
+        for (auto &th : pool) th.join();
+        HIP_TRY(hipMemcpy2D(d0 + zb * g.plane, g.pitch_x * 4, h0.data(), X * 4, X * 4, n * Y, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy2D(d1 + zb * g.plane, g.pitch_x * 4, h1.data(), X * 4, X * 4, n * Y, hipMemcpyHostToDevice));
+    }
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_init_jacobi(fdtdx_ctx *ctx, const char *name)
+{
+    float *d;
+    int rc = find_cube(ctx, name, &d);
+    if (rc) return rc;
+    const fdtdx_geometry &g = ctx->g;
+    const uint64_t X = ctx->cfg.X, Y = ctx->cfg.Y;
+    std::vector<float> h(Y * X);
+    for (uint64_t z = 0; z < g.local_planes; z++) {
+        const uint64_t k = g.first_global + z;
+        for (uint64_t j = 0; j < Y; j++)
+            for (uint64_t i = 0; i < X; i++)  // jacobi.cu:415: i - j + 1.0/(k+1) in double
+                h[j * X + i] = (float)((double)((long long)i - (long long)j) + 1.0 / (double)(k + 1));
+        HIP_TRY(hipMemcpy2D(d + z * g.plane, g.pitch_x * 4, h.data(), X * 4, X * 4, Y, hipMemcpyHostToDevice));
+    }
+    return FDTDX_OK;
+}
+
+// ---- sweep dispatch (stencil.h:684-768) ------------------------------------------------------------
+static int check_program(const fdtdx_ctx *ctx, const fdtdx_program *prog, int *radius)
+{
+    if (!prog) return fail(FDTDX_ERR_INVALID, "null program");
+    int r = 1;
+    if (prog->kind == FDTDX_STAR) {
+        r = (int)prog->radius;
+        if (r < 1 || r > 8) return fail(FDTDX_ERR_UNSUPPORTED, "star radius %d outside 1..8", r);
+    } else if (prog->kind != FDTDX_SPC13 && prog->kind != FDTDX_JACOBI7) {
+        return fail(FDTDX_ERR_UNSUPPORTED, "unknown program kind %u", prog->kind);
+    }
+    if (prog->order != FDTDX_ORDER_CHAIN && prog->order != FDTDX_ORDER_GOLDEN) return fail(FDTDX_ERR_INVALID, "unknown order %u", prog->order);
+    if ((uint32_t)r > ctx->cfg.M) return fail(FDTDX_ERR_INVALID, "program radius %d exceeds the context's ghost width M=%u", r, ctx->cfg.M);
+    *radius = r;
+    return FDTDX_OK;
+}
+
+// Default tile shape per radius for rows of about 512 cells; refined by on-device measurement.
+static void default_shape(int kind, int r, int *tq, int *ly, int *ry)
+{
+    if (kind == FDTDX_SPC13) {
+        *tq = 64, *ly = 8, *ry = 2;
+        return;
+    }
+    switch (r) {
+    case 1: *tq = 128, *ly = 8, *ry = 2; break;
+    case 2: *tq = 128, *ly = 8, *ry = 2; break;
+    case 3: *tq = 64, *ly = 16, *ry = 2; break;
+    case 4: *tq = 64, *ly = 16, *ry = 2; break;
+    case 5: *tq = 32, *ly = 16, *ry = 2; break;
+    case 6: *tq = 32, *ly = 16, *ry = 2; break;
+    default: *tq = 32, *ly = 32, *ry = 1; break;
+    }
+}
+
+static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx_program *prog, uint64_t z_lo, uint64_t z_hi, void *stream)
+{
+    int r;
+    int rc = check_program(ctx, prog, &r);
+    if (rc) return rc;
+    const fdtdx_geometry &g = ctx->g;
+    if (z_lo < (uint64_t)r || z_hi > g.local_planes - r || z_lo > z_hi)
+        return fail(FDTDX_ERR_INVALID, "plane range [%llu,%llu) outside [%d,%llu)", (unsigned long long)z_lo, (unsigned long long)z_hi, r, (unsigned long long)(g.local_planes - r));
+    if (z_lo == z_hi) return FDTDX_OK;
+    if (out == in) return fail(FDTDX_ERR_INVALID, "sweep cannot run in place");
+
+    SweepParams p;
+    p.in = in;
+    p.out = out;
+    p.plane = (long long)g.plane;
+    p.px = (int)g.pitch_x;
+    p.pxq = (int)(g.pitch_x / 4);
+    p.nx = (int)ctx->cfg.X;
+    p.ny = (int)ctx->cfg.Y;
+    p.h = r;
+    p.z_lo = (int)z_lo;
+    p.z_hi = (int)z_hi;
+    memset(p.c, 0, sizeof(p.c));
+    memcpy(p.c, prog->coef, 13 * sizeof(float));
+
+    int tq, ly, ry, threads, lds;
+    void (*launch)(const SweepParams &, dim3, hipStream_t) = nullptr;
+    int dtq, dly, dry;
+    default_shape(prog->kind, r, &dtq, &dly, &dry);
+    if (prog->kind == FDTDX_SPC13) {
+        const SpcVariantInfo *best = nullptr;
+        int idx = 0;
+        for (int i = 0; i < num_spc_variants(); i++) {
+            const SpcVariantInfo *v = spc_variant(i);
+            if (v->order != (int)prog->order) continue;
+            if (ctx->opt_variant >= 0 ? (idx == ctx->opt_variant) : (!best || (v->tq == dtq && v->ly == dly && v->ry == dry))) best = v;
+            idx++;
+        }
+        if (!best) return fail(FDTDX_ERR_UNSUPPORTED, "no spc13 kernel for order %u", prog->order);
+        tq = best->tq, ly = best->ly, ry = best->ry, threads = best->threads, lds = best->lds_bytes, launch = best->launch;
+    } else {
+        int ord = (prog->kind == FDTDX_STAR) ? (prog->order == FDTDX_ORDER_CHAIN ? ORD_STAR_CHAIN : ORD_STAR_GOLDEN)
+                                             : (prog->order == FDTDX_ORDER_CHAIN ? ORD_JACOBI_CHAIN : ORD_JACOBI_GOLDEN);
+        const VariantInfo *best = nullptr;
+        int idx = 0;
+        for (int i = 0; i < num_variants(); i++) {
+            const VariantInfo *v = variant(i);
+            if (v->M != r || v->order != ord) continue;
+            if (ctx->opt_variant >= 0 ? (idx == ctx->opt_variant) : (!best || (v->tq == dtq && v->ly == dly && v->ry == dry))) best = v;
+            idx++;
+        }
+        if (!best) return fail(FDTDX_ERR_UNSUPPORTED, "no kernel for radius %d order %u variant %lld", r, prog->order, (long long)ctx->opt_variant);
+        tq = best->tq, ly = best->ly, ry = best->ry, threads = best->threads, lds = best->lds_bytes, launch = best->launch;
+    }
+
+    const int nq = (p.nx + 3) / 4;                      // quads that hold logical cells
+    const int rows = p.ny - 2 * r;                      // computed rows
+    const int gx = (nq + tq - 1) / tq, gy = (rows + ly * ry - 1) / (ly * ry);
+    const long long nz = (long long)(z_hi - z_lo);
+    long long chunks = ctx->opt_zchunks;
+    if (chunks <= 0) {
+        // aim for ~8 workgroups per CU over the chip (256 CUs) while keeping the 2r-plane
+        // pipeline fill below ~1/8 of a chunk
+        const long long tiles = (long long)gx * gy;
+        chunks = std::max<long long>(1, (2048 + tiles - 1) / tiles);
+        const long long min_len = std::max<long long>(16LL * r, 16);
+        chunks = std::min(chunks, std::max<long long>(1, nz / min_len));
+    }
+    chunks = std::max<long long>(1, std::min(chunks, nz));
+    p.zchunk = (int)((nz + chunks - 1) / chunks);
+    const int gz = (int)((nz + p.zchunk - 1) / p.zchunk);
+    if (gy > 65535 || gz > 65535) return fail(FDTDX_ERR_UNSUPPORTED, "grid too large (%d,%d,%d)", gx, gy, gz);
+
+    launch(p, dim3(gx, gy, gz), (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    snprintf(ctx->last_launch, sizeof(ctx->last_launch), "kind=%u r=%d order=%u tile=%dx%d(quads x rows) threads=%d ry=%d lds=%d grid=%dx%dx%d zchunk=%d",
+             prog->kind, r, prog->order, tq, ly * ry, threads, ry, lds, gx, gy, gz, p.zchunk);
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_propagate_ptr(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx_program *prog, uint64_t z_lo, uint64_t z_hi, void *stream)
+{
+    if (!ctx || !out || !in) return fail(FDTDX_ERR_INVALID, "null argument");
+    return launch_sweep(ctx, out, in, prog, z_lo, z_hi, stream);
+}
+
+extern "C" int fdtdx_propagate_planes(fdtdx_ctx *ctx, const char *out, const char *in, const fdtdx_program *prog, uint64_t z_lo, uint64_t z_hi, void *stream)
+{
+    float *po, *pi;
+    int rc = find_cube(ctx, out, &po);
+    if (rc) return rc;
+    rc = find_cube(ctx, in, &pi);
+    if (rc) return rc;
+    return launch_sweep(ctx, po, pi, prog, z_lo, z_hi, stream);
+}
+
+extern "C" int fdtdx_propagate(fdtdx_ctx *ctx, const char *out, const char *in, const fdtdx_program *prog, void *stream)
+{
+    if (!ctx) return fail(FDTDX_ERR_INVALID, "null context");
+    int r;
+    int rc = check_program(ctx, prog, &r);
+    if (rc) return rc;
+    // Planes this rank updates: stencil.h:690 (nz) -- every owned plane except the global shell.
+    // Ghost planes are M deep, the program may be shallower (r <= M): the update range is
+    // clipped to what the ghosts support.
+    const fdtdx_geometry &g = ctx->g;
+    uint64_t lo = g.ghost_lo ? g.ghost_lo : (uint64_t)r;
+    uint64_t hi = g.ghost_hi ? g.local_planes - g.ghost_hi : g.local_planes - r;
+    return fdtdx_propagate_planes(ctx, out, in, prog, lo, hi, stream);
+}
+
+extern "C" int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const fdtdx_program *prog, uint32_t steps, void *stream)
+{
+    if (!ctx) return fail(FDTDX_ERR_INVALID, "null context");
+    if (ctx->cfg.nprocs != 1) return fail(FDTDX_ERR_UNSUPPORTED, "fdtdx_sweep runs whole time loops on one rank only; use propagate + halo exchange per step");
+    const char *out = a, *in = b;
+    for (uint32_t t = 0; t < steps; t++) {
+        int rc = fdtdx_propagate(ctx, out, in, prog, stream);
+        if (rc) return rc;
+        std::swap(out, in);
+    }
+    return FDTDX_OK;
+}
+
+// ---- halo regions (stencil.h:639-647) ---------------------------------------------------------------
+extern "C" int fdtdx_halo_region(fdtdx_ctx *ctx, const char *name, int side, int what, float **ptr, size_t *count)
+{
+    float *d;
+    int rc = find_cube(ctx, name, &d);
+    if (rc) return rc;
+    if (!ptr || !count || (side != 0 && side != 1) || (what != 0 && what != 1)) return fail(FDTDX_ERR_INVALID, "bad halo_region argument");
+    const fdtdx_geometry &g = ctx->g;
+    const uint64_t M = ctx->cfg.M;
+    const bool has = side == 0 ? g.ghost_lo > 0 : g.ghost_hi > 0;
+    if (!has) {
+        *ptr = nullptr;
+        *count = 0;
+        return FDTDX_OK;
+    }
+    uint64_t first;
+    if (side == 0)
+        first = (what == 0) ? M : 0;  // send the first M owned planes, receive into the M ghost planes below
+    else
+        first = (what == 0) ? g.local_planes - 2 * M : g.local_planes - M;
+    *ptr = d + first * g.plane;
+    *count = (size_t)(M * g.plane);
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_set_option(fdtdx_ctx *ctx, const char *key, int64_t value)
+{
+    if (!ctx || !key) return fail(FDTDX_ERR_INVALID, "null argument");
+    if (!strcmp(key, "zchunks"))
+        ctx->opt_zchunks = value;
+    else if (!strcmp(key, "variant"))
+        ctx->opt_variant = value;
+    else
+        return fail(FDTDX_ERR_INVALID, "unknown option '%s'", key);
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_last_launch_info(const fdtdx_ctx *ctx, char *buf, size_t len)
+{
+    if (!ctx || !buf || !len) return fail(FDTDX_ERR_INVALID, "null argument");
+    snprintf(buf, len, "%s", ctx->last_launch);
+    return FDTDX_OK;
+}

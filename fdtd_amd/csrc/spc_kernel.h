@@ -1,0 +1,211 @@
+// spc_kernel.h -- 13-point "special" stencil sweep (fdtdspc.cu:64-73) for gfx950.
+//
+// Replaces prop_center_bf_kernel (stencil.h:75-93), which issues 13 uncached-pattern global
+// loads per cell.  Here a workgroup keeps planes z-1, z, z+1 of its tile (plus a one-cell halo
+// INCLUDING corners, because the stencil has in-plane and cross-plane diagonals) in a ring of
+// four LDS plane images; each plane is read from HBM once per tile with coalesced 16-byte loads
+// and every neighbour, diagonal or not, is an LDS read.  Four ring slots let the loads of
+// plane z+2 land while plane z is being computed with a single barrier per plane.
+#pragma once
+#include "sweep_common.h"
+
+namespace fdtdx {
+
+template <int TQ, int LY, int RY, int GOLDEN>
+__global__ __launch_bounds__(TQ *LY) void spc13_sweep_kernel(const SweepParams p)
+{
+    constexpr int NT = TQ * LY;
+    constexpr int CY = LY * RY;
+    constexpr int LROWS = CY + 2;
+    constexpr int LPQ = TQ + 2;
+    constexpr int NHY = 2 * LPQ;             // full halo rows (corners included)
+    constexpr int NHQ = NHY + 2 * CY;        // + left/right halo quads
+    constexpr int NHK = (NHQ + NT - 1) / NT;
+    constexpr int SLOT = LROWS * LPQ;
+
+    __shared__ float4 ring[4 * SLOT];
+
+    const int t = threadIdx.x;
+    const int tx = t % TQ, ty = t / TQ;
+    const int q0 = blockIdx.x * TQ;
+    const int y0 = 1 + blockIdx.y * CY;
+    const int zs = p.z_lo + blockIdx.z * p.zchunk;
+    const int ze = min(zs + p.zchunk, p.z_hi);
+    if (zs >= ze) return;
+
+    const int qx = q0 + tx;
+    const bool qok = qx < p.pxq;
+    int goff[RY];
+    bool rok[RY], cok[RY];
+#pragma unroll
+    for (int j = 0; j < RY; j++) {
+        const int y = y0 + ty + j * LY;
+        rok[j] = qok && (y < p.ny);
+        cok[j] = qok && (y < p.ny - 1);
+        goff[j] = y * p.px + 4 * qx;
+    }
+    const int x0 = 4 * qx;
+    const bool m0 = (x0 + 0 >= 1) && (x0 + 0 < p.nx - 1);
+    const bool m1 = (x0 + 1 >= 1) && (x0 + 1 < p.nx - 1);
+    const bool m2 = (x0 + 2 >= 1) && (x0 + 2 < p.nx - 1);
+    const bool m3 = (x0 + 3 >= 1) && (x0 + 3 < p.nx - 1);
+    const bool mall = m0 && m1 && m2 && m3;
+    const bool many = m0 || m1 || m2 || m3;
+
+    int hgoff[NHK], hloff[NHK];
+    bool hok[NHK], hin[NHK];
+#pragma unroll
+    for (int k = 0; k < NHK; k++) {
+        const int hidx = t + k * NT;
+        int lrow, lcol;
+        if (hidx < NHY) {
+            const int rr = hidx / LPQ;
+            lcol = hidx % LPQ;
+            lrow = (rr == 0) ? 0 : CY + 1;
+        } else {
+            const int h2 = hidx - NHY;
+            lrow = 1 + (h2 >> 1);
+            lcol = (h2 & 1) ? TQ + 1 : 0;
+        }
+        const int gy = y0 - 1 + lrow;
+        const int gq = q0 - 1 + lcol;
+        hin[k] = (k < NHK - 1) || (hidx < NHQ);
+        hok[k] = hin[k] && (gy < p.ny) && (gq >= 0) && (gq < p.pxq);
+        hgoff[k] = gy * p.px + 4 * gq;
+        hloff[k] = lrow * LPQ + lcol;
+    }
+    int ownl[RY];
+#pragma unroll
+    for (int j = 0; j < RY; j++) ownl[j] = (1 + ty + j * LY) * LPQ + 1 + tx;
+
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // prologue: planes zs-1 and zs straight into their ring slots, plane zs+1 into registers
+    const float *pl = p.in + (long long)(zs - 1) * p.plane;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        float4 *slot = ring + ((zs - 1 + s) & 3) * SLOT;
+#pragma unroll
+        for (int j = 0; j < RY; j++) slot[ownl[j]] = rok[j] ? ld4(pl + goff[j]) : zero4;
+#pragma unroll
+        for (int k = 0; k < NHK; k++)
+            if (hin[k]) slot[hloff[k]] = hok[k] ? ld4(pl + hgoff[k]) : zero4;
+        pl += p.plane;
+    }
+    float4 nxt[RY], hv[NHK];
+#pragma unroll
+    for (int j = 0; j < RY; j++) nxt[j] = rok[j] ? ld4(pl + goff[j]) : zero4;
+#pragma unroll
+    for (int k = 0; k < NHK; k++) hv[k] = hok[k] ? ld4(pl + hgoff[k]) : zero4;
+    float *po = p.out + (long long)zs * p.plane;
+
+    float c[13];
+#pragma unroll
+    for (int i = 0; i < 13; i++) c[i] = p.c[i];
+
+    for (int z = zs; z < ze; z++) {
+        float4 *sp = ring + ((z + 1) & 3) * SLOT;
+#pragma unroll
+        for (int j = 0; j < RY; j++) sp[ownl[j]] = nxt[j];
+#pragma unroll
+        for (int k = 0; k < NHK; k++)
+            if (hin[k]) sp[hloff[k]] = hv[k];
+        if (z + 1 < ze) {
+            pl += p.plane;
+#pragma unroll
+            for (int j = 0; j < RY; j++) nxt[j] = rok[j] ? ld4(pl + goff[j]) : zero4;
+#pragma unroll
+            for (int k = 0; k < NHK; k++) hv[k] = hok[k] ? ld4(pl + hgoff[k]) : zero4;
+        }
+        __syncthreads();
+
+        const float4 *s0 = ring + (z & 3) * SLOT;
+        const float4 *sm = ring + ((z - 1) & 3) * SLOT;
+#pragma unroll
+        for (int j = 0; j < RY; j++) {
+            if (!(cok[j] && many)) continue;
+            const int o = ownl[j];
+            const float4 C = s0[o];
+            const float Lw = reinterpret_cast<const float *>(s0 + o - 1)[3];
+            const float Rx = reinterpret_cast<const float *>(s0 + o + 1)[0];
+            const float4 U = s0[o + LPQ], D = s0[o - LPQ];
+            const float URx = reinterpret_cast<const float *>(s0 + o + LPQ + 1)[0];
+            const float DLw = reinterpret_cast<const float *>(s0 + o - LPQ - 1)[3];
+            const float4 ZP = sp[o], ZM = sm[o];
+            const float4 ZPU = sp[o + LPQ], ZMD = sm[o - LPQ];
+            const float ZPURx = reinterpret_cast<const float *>(sp + o + LPQ + 1)[0];
+            const float ZMDLw = reinterpret_cast<const float *>(sm + o - LPQ - 1)[3];
+
+            const float cv[4] = {C.x, C.y, C.z, C.w};
+            const float xp[4] = {C.y, C.z, C.w, Rx}, xm[4] = {Lw, C.x, C.y, C.z};
+            const float yp[4] = {U.x, U.y, U.z, U.w}, ym[4] = {D.x, D.y, D.z, D.w};
+            const float zp[4] = {ZP.x, ZP.y, ZP.z, ZP.w}, zm[4] = {ZM.x, ZM.y, ZM.z, ZM.w};
+            const float ypxp[4] = {U.y, U.z, U.w, URx}, ymxm[4] = {DLw, D.x, D.y, D.z};
+            const float zpyp[4] = {ZPU.x, ZPU.y, ZPU.z, ZPU.w}, zmym[4] = {ZMD.x, ZMD.y, ZMD.z, ZMD.w};
+            const float zpypxp[4] = {ZPU.y, ZPU.z, ZPU.w, ZPURx}, zmymxm[4] = {ZMDLw, ZMD.x, ZMD.y, ZMD.z};
+            float acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float a = c[0] * cv[i];
+                if constexpr (GOLDEN) {
+                    a = a + (c[1] * xp[i] + c[2] * xm[i]);
+                    a = a + (c[3] * yp[i] + c[4] * ym[i]);
+                    a = a + (c[5] * zp[i] + c[6] * zm[i]);
+                    a = a + (c[7] * ypxp[i] + c[8] * ymxm[i]);
+                    a = a + (c[9] * zpyp[i] + c[10] * zmym[i]);
+                    a = a + (c[11] * zpypxp[i] + c[12] * zmymxm[i]);
+                } else {
+                    a = __builtin_fmaf(c[1], xp[i], a);
+                    a = __builtin_fmaf(c[2], xm[i], a);
+                    a = __builtin_fmaf(c[3], yp[i], a);
+                    a = __builtin_fmaf(c[4], ym[i], a);
+                    a = __builtin_fmaf(c[5], zp[i], a);
+                    a = __builtin_fmaf(c[6], zm[i], a);
+                    a = __builtin_fmaf(c[7], ypxp[i], a);
+                    a = __builtin_fmaf(c[8], ymxm[i], a);
+                    a = __builtin_fmaf(c[9], zpyp[i], a);
+                    a = __builtin_fmaf(c[10], zmym[i], a);
+                    a = __builtin_fmaf(c[11], zpypxp[i], a);
+                    a = __builtin_fmaf(c[12], zmymxm[i], a);
+                }
+                acc[i] = a;
+            }
+            float *op = po + goff[j];
+            if (mall) {
+                *reinterpret_cast<float4 *>(op) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            } else {
+                if (m0) op[0] = acc[0];
+                if (m1) op[1] = acc[1];
+                if (m2) op[2] = acc[2];
+                if (m3) op[3] = acc[3];
+            }
+        }
+        po += p.plane;
+    }
+}
+
+template <int TQ, int LY, int RY, int GOLDEN>
+void spc13_launch(const SweepParams &p, dim3 grid, hipStream_t s)
+{
+    hipLaunchKernelGGL((spc13_sweep_kernel<TQ, LY, RY, GOLDEN>), grid, dim3(TQ * LY), 0, s, p);
+}
+
+template <int TQ, int LY, int RY, int GOLDEN>
+struct SpcRegistrar {
+    SpcRegistrar()
+    {
+        SpcVariantInfo v;
+        v.order = GOLDEN;
+        v.tq = TQ;
+        v.ly = LY;
+        v.ry = RY;
+        v.threads = TQ * LY;
+        v.lds_bytes = 4 * (LY * RY + 2) * (TQ + 2) * 16;
+        v.launch = &spc13_launch<TQ, LY, RY, GOLDEN>;
+        register_spc_variant(v);
+    }
+};
+
+#define FDTDX_SPC_VARIANT(TQ, LY, RY, GOLDEN) \
+    static ::fdtdx::SpcRegistrar<TQ, LY, RY, GOLDEN> spcreg_##TQ##_##LY##_##RY##_##GOLDEN;
+
+}  // namespace fdtdx

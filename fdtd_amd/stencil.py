@@ -1,0 +1,136 @@
+"""Python face of the reference's `Stencil<DataType,Z,Y,X,M,...>` host class (stencil.h:357-842).
+
+Method names and argument meaning follow the reference so that driver code reads the same
+(`mallocCube`, `transferCubeToGPU`, `propagate`, `transferCubeToCPU`, ...).  Two differences
+that a C ABI forces:
+  * the per-cell device lambda becomes a `Program` picked from the closed set the reference
+    ships (fdtd_amd.lib.make_program);
+  * API misuse raises FdtdxError instead of tripping an assert (stencil.h:443,470,555,...).
+All work is done by libfdtdx.so through ctypes; nothing here computes.
+"""
+import ctypes
+
+import numpy as np
+
+from . import lib as _lib
+
+
+class Stencil:
+    def __init__(self, Z, Y, X, M, rank=0, nprocs=1, device=-1, pitch_x=0):
+        """stencil.h:385-413.  rank/nprocs replace MPI::COMM_WORLD rank/size."""
+        self._L = _lib.load()
+        self.Z, self.Y, self.X, self.M = Z, Y, X, M
+        cfg = _lib.Config(Z, Y, X, M, rank, nprocs, device, pitch_x, 0)
+        h = ctypes.c_void_p()
+        _lib.check(self._L.fdtdx_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self._h = h
+        g = _lib.Geometry()
+        _lib.check(self._L.fdtdx_get_geometry(self._h, ctypes.byref(g)))
+        self.geometry = g
+
+    # -- lifetime ------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fdtdx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- stencil.h:420-438 ---------------------------------------------------------------
+    def getRank(self):
+        return self._L.fdtdx_rank(self._h)
+
+    def getProcs(self):
+        return self._L.fdtdx_nprocs(self._h)
+
+    def sync(self):
+        _lib.check(self._L.fdtdx_sync(self._h))
+
+    # -- pool: stencil.h:553-582, 468-477 -----------------------------------------------
+    def mallocCube(self, name, create_halo=False):
+        """create_halo is accepted for source compatibility; ghost planes live inside the cube
+        (the side buffers of stencil.h:560-574 are not needed)."""
+        _lib.check(self._L.fdtdx_malloc_cube(self._h, name.encode()))
+
+    def attachCube(self, name, device_ptr, nbytes):
+        _lib.check(self._L.fdtdx_attach_cube(self._h, name.encode(), ctypes.c_void_p(device_ptr), nbytes))
+
+    def free(self, name):
+        _lib.check(self._L.fdtdx_free(self._h, name.encode()))
+
+    def getCube(self, name):
+        p = ctypes.c_void_p()
+        _lib.check(self._L.fdtdx_get_cube(self._h, name.encode(), ctypes.byref(p)))
+        return p.value
+
+    # -- transfers: stencil.h:596-637 -----------------------------------------------------
+    def transferCubeToGPU(self, name, cpu):
+        cpu = np.ascontiguousarray(cpu, np.float32)
+        assert cpu.shape == (self.Z, self.Y, self.X), cpu.shape
+        _lib.check(self._L.fdtdx_transfer_cube_to_gpu(self._h, name.encode(), cpu.ctypes.data_as(ctypes.c_void_p)))
+
+    def transferCubeToCPU(self, cpu, name):
+        assert cpu.dtype == np.float32 and cpu.flags["C_CONTIGUOUS"] and cpu.shape == (self.Z, self.Y, self.X)
+        _lib.check(self._L.fdtdx_transfer_cube_to_cpu(self._h, cpu.ctypes.data_as(ctypes.c_void_p), name.encode()))
+
+    def uploadLocal(self, name, local):
+        local = np.ascontiguousarray(local, np.float32)
+        assert local.shape == (self.geometry.local_planes, self.Y, self.X), local.shape
+        _lib.check(self._L.fdtdx_upload_local(self._h, name.encode(), local.ctypes.data_as(ctypes.c_void_p)))
+
+    def downloadOwned(self, name):
+        out = np.empty((self.geometry.owned_planes, self.Y, self.X), np.float32)
+        _lib.check(self._L.fdtdx_download_owned(self._h, out.ctypes.data_as(ctypes.c_void_p), name.encode()))
+        return out
+
+    def initMt(self, name_p0, name_p1):
+        """fdtd1.cu:21-31 initial fields, generated for this slab's planes."""
+        _lib.check(self._L.fdtdx_init_mt(self._h, name_p0.encode(), name_p1.encode()))
+
+    def initJacobi(self, name):
+        """jacobi.cu:412-417 initial field."""
+        _lib.check(self._L.fdtdx_init_jacobi(self._h, name.encode()))
+
+    # -- sweeps: stencil.h:684-768 ---------------------------------------------------------
+    def propagate(self, output, input, program, stream=None, spill=True):
+        """One sweep output = f(input).  `spill` (a launch-bounds hint in the reference,
+        stencil.h:696-699) is accepted and ignored."""
+        _lib.check(self._L.fdtdx_propagate(self._h, output.encode(), input.encode(), ctypes.byref(program),
+                                           ctypes.c_void_p(stream or 0)))
+
+    def propagatePlanes(self, output, input, program, z_lo, z_hi, stream=None):
+        _lib.check(self._L.fdtdx_propagate_planes(self._h, output.encode(), input.encode(), ctypes.byref(program),
+                                                  z_lo, z_hi, ctypes.c_void_p(stream or 0)))
+
+    def sweep(self, a, b, program, steps, stream=None):
+        """The drivers' whole time loop on one rank (fdtd1.cu:68-80)."""
+        _lib.check(self._L.fdtdx_sweep(self._h, a.encode(), b.encode(), ctypes.byref(program), steps,
+                                       ctypes.c_void_p(stream or 0)))
+
+    # -- halo regions: stencil.h:639-647 --------------------------------------------------
+    def haloRegion(self, name, side, what):
+        """(device pointer, float count) of the planes to send (what=0) / receive (what=1)
+        on side 0 (rank-1) or 1 (rank+1); (None, 0) where there is no neighbour."""
+        p = ctypes.c_void_p()
+        n = ctypes.c_size_t()
+        _lib.check(self._L.fdtdx_halo_region(self._h, name.encode(), side, what, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    # -- tuning ------------------------------------------------------------------------------
+    def setOption(self, key, value):
+        _lib.check(self._L.fdtdx_set_option(self._h, key.encode(), int(value)))
+
+    def lastLaunchInfo(self):
+        buf = ctypes.create_string_buffer(256)
+        _lib.check(self._L.fdtdx_last_launch_info(self._h, buf, 256))
+        return buf.value.decode()

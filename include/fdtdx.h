@@ -1,0 +1,168 @@
+/*
+ * fdtdx.h -- C ABI of the MI355X (gfx950) stencil sweep engine.
+ *
+ * Drop-in boundary for the `Stencil<...>` host class of the reference (stencil.h:357-842) and
+ * the per-step sweep it dispatches (stencil.h:684-768).  Device lambdas cannot cross a C ABI,
+ * so the per-cell arithmetic is selected from the closed set of programs the reference ships
+ * (fdtd1..8.cu, fdtdspc.cu, jacobi.cu) through `fdtdx_program`.
+ *
+ * Conventions
+ *   - every function returns FDTDX_OK (0) or an FDTDX_ERR_* code and never aborts; the text of
+ *     the last failure on the calling thread is available from fdtdx_last_error().  (The
+ *     reference asserts/aborts instead: stencil.h:16-22; the C++ mirror in fdtdx/stencil.hpp
+ *     restores that behaviour on top of these codes.)
+ *   - all pointers are plain host or device pointers; `stream` is a hipStream_t passed as
+ *     void* (NULL = the default stream).  Launches are asynchronous on that stream.
+ *   - device cubes are laid out [local plane][y][PX] fp32, x unit-stride, PX = padded pitch.
+ *   - one context = one z-slab = one GPU = one process (one MPI rank in the reference).
+ */
+#ifndef FDTDX_H
+#define FDTDX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fdtdx_ctx fdtdx_ctx;
+
+enum {
+    FDTDX_OK = 0,
+    FDTDX_ERR_INVALID = 1,     /* bad argument (reference: assert, stencil.h:387,403) */
+    FDTDX_ERR_NOTFOUND = 2,    /* unknown buffer name (reference: assert, stencil.h:470,482,580) */
+    FDTDX_ERR_EXISTS = 3,      /* duplicate buffer name (reference: assert, stencil.h:443,555) */
+    FDTDX_ERR_HIP = 4,         /* HIP runtime failure (reference: CUDA_ASSERT, stencil.h:16-22) */
+    FDTDX_ERR_UNSUPPORTED = 5, /* program/shape outside what the kernels cover */
+    FDTDX_ERR_NOMEM = 6
+};
+
+/* Which per-cell program runs (the device lambdas of the shipped drivers). */
+enum {
+    FDTDX_STAR = 0,    /* fdtdN.cu:61-64 .. fdtd8.cu:82-93: radius-M star, coef[0..6] =
+                          {centre, x+, x-, y+, y-, z+, z-} shared by every radius r */
+    FDTDX_SPC13 = 1,   /* fdtdspc.cu:64-73: coef[0..12] in lambda order */
+    FDTDX_JACOBI7 = 2  /* jacobi.cu:31-38: coef[0..6] = {cc, ce, cw, cs, cn, ct, cb},
+                          evaluated ce*E+cw*W+cs*S+cn*N+ct*T+cb*B+cc*C */
+};
+
+/* Floating-point association of the sum. */
+enum {
+    FDTDX_ORDER_CHAIN = 0,  /* device order: flat left-to-right, every "+ c*v" one FMA
+                               (nvcc -fmad=true, CMakeLists.txt:5) */
+    FDTDX_ORDER_GOLDEN = 1  /* host golden order: parenthesised (+r,-r) pairs, separate IEEE
+                               mul/add (fdtd1.cu:46-49, fdtdspc.cu:46-52, jacobi.cu:478-485);
+                               bit-identical to the reference CPU loop */
+};
+
+typedef struct {
+    uint32_t kind;   /* FDTDX_STAR | FDTDX_SPC13 | FDTDX_JACOBI7 */
+    uint32_t radius; /* M for FDTDX_STAR (1..8); ignored (1) otherwise */
+    uint32_t order;  /* FDTDX_ORDER_* */
+    uint32_t reserved;
+    float coef[16];
+} fdtdx_program;
+
+/* Replaces the template arguments + MPI rank/size of `Stencil` (stencil.h:357,385-413). */
+typedef struct {
+    uint64_t Z, Y, X;     /* global logical grid (ZSize, YSize, XSize) */
+    uint32_t M;           /* ghost/shell width: the radius the cubes are sized for (1..8) */
+    uint32_t rank;        /* this slab's index along z (MPI rank) */
+    uint32_t nprocs;      /* number of z-slabs (MPI size) */
+    int32_t device;       /* HIP device ordinal; -1 = keep the current device */
+    uint32_t pitch_x;     /* row pitch in floats, multiple of 32; 0 = (X/32+1)*32 as the reference's
+                             PADDINGR default for M<=2 (stencil.h:357) */
+    uint32_t flags;       /* reserved, 0 */
+} fdtdx_config;
+
+/* z-slab decomposition and padded layout (stencil.h:398-412; formulas restated in DESIGN.md). */
+typedef struct {
+    uint64_t pitch_x;       /* PX: floats per row */
+    uint64_t plane;         /* Y*PX: floats per plane */
+    uint64_t owned_begin;   /* mpiOff[rank]: first global plane owned */
+    uint64_t owned_planes;  /* mpiSize[rank] */
+    uint64_t ghost_lo;      /* M if rank>0 else 0: ghost planes below the owned range */
+    uint64_t ghost_hi;      /* M if rank<nprocs-1 else 0 */
+    uint64_t local_planes;  /* ghost_lo + owned_planes + ghost_hi  (size2/plane) */
+    uint64_t first_global;  /* global z of local plane 0          (off2/plane) */
+    uint64_t update_lo;     /* first local plane a sweep writes: M */
+    uint64_t update_hi;     /* one past the last local plane a sweep writes: local_planes-M */
+    uint64_t cube_elems;    /* local_planes*plane */
+} fdtdx_geometry;
+
+/* Pure host function (no GPU): the decomposition for any rank. stencil.h:398-412. */
+int fdtdx_decompose(const fdtdx_config *cfg, fdtdx_geometry *out);
+
+/* Stencil::Stencil / ~Stencil (stencil.h:385-418), minus MPI_Init/Finalize which belong to the
+ * launcher (torch.distributed / RCCL) in this design. */
+int fdtdx_create(const fdtdx_config *cfg, fdtdx_ctx **out);
+int fdtdx_destroy(fdtdx_ctx *ctx);
+const char *fdtdx_last_error(void);
+int fdtdx_get_geometry(const fdtdx_ctx *ctx, fdtdx_geometry *out);
+
+/* Stencil::getRank / getProcs / sync (stencil.h:420-433). */
+int fdtdx_rank(const fdtdx_ctx *ctx);
+int fdtdx_nprocs(const fdtdx_ctx *ctx);
+int fdtdx_sync(fdtdx_ctx *ctx);
+
+/* Stencil::mallocCube / free / getCube (stencil.h:553-582, 468-477).  Cubes are zero-filled.
+ * attach_cube registers caller-owned device memory (>= cube_elems floats) under a name; the
+ * context never frees it. */
+int fdtdx_malloc_cube(fdtdx_ctx *ctx, const char *name);
+int fdtdx_attach_cube(fdtdx_ctx *ctx, const char *name, void *device_ptr, size_t bytes);
+int fdtdx_free(fdtdx_ctx *ctx, const char *name);
+int fdtdx_get_cube(fdtdx_ctx *ctx, const char *name, float **device_ptr);
+
+/* Stencil::transferCubeToGPU (stencil.h:596-608): `host` is the whole unpadded [Z][Y][X] grid;
+ * this slab's planes (ghosts included) are padded and copied to the device. */
+int fdtdx_transfer_cube_to_gpu(fdtdx_ctx *ctx, const char *name, const float *host);
+/* Stencil::transferCubeToCPU (stencil.h:610-622), local part: writes the planes this rank OWNS
+ * into their place in the unpadded global grid `host`.  The cross-rank gather/broadcast of
+ * stencil.h:623-636 is done by the caller's communicator (fdtd_amd.slab.gather_cube). */
+int fdtdx_transfer_cube_to_cpu(fdtdx_ctx *ctx, float *host, const char *name);
+/* Same transfers for a caller that holds only its own planes: `host_local` is
+ * [local_planes][Y][X] (upload) / [owned_planes][Y][X] (download). */
+int fdtdx_upload_local(fdtdx_ctx *ctx, const char *name, const float *host_local);
+int fdtdx_download_owned(fdtdx_ctx *ctx, float *host_owned, const char *name);
+
+/* Initial fields of the fdtdN/fdtdspc drivers generated in place (fdtd1.cu:21-31:
+ * std::mt19937_64(19950918+z) per global plane, draws p0 then p1 per cell) and of jacobi.cu
+ * (jacobi.cu:412-417: i - j + 1/(k+1)).  Host-generated, then uploaded. */
+int fdtdx_init_mt(fdtdx_ctx *ctx, const char *name_p0, const char *name_p1);
+int fdtdx_init_jacobi(fdtdx_ctx *ctx, const char *name);
+
+/* Stencil::propagate (stencil.h:684-768): one sweep out = f(in) over every plane this rank
+ * updates ([update_lo, update_hi)), interior [h, n-h) in y and x (h = program radius). */
+int fdtdx_propagate(fdtdx_ctx *ctx, const char *out, const char *in, const fdtdx_program *prog,
+                    void *stream);
+/* The same sweep restricted to local planes [z_lo, z_hi): the boundary-planes-first / interior
+ * split that replaces propagateHalo{Top,Buttom}Backup (stencil.h:770-808). */
+int fdtdx_propagate_planes(fdtdx_ctx *ctx, const char *out, const char *in, const fdtdx_program *prog,
+                           uint64_t z_lo, uint64_t z_hi, void *stream);
+/* Raw-pointer form for callers that manage their own cubes (same layout/geometry as ctx). */
+int fdtdx_propagate_ptr(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx_program *prog,
+                        uint64_t z_lo, uint64_t z_hi, void *stream);
+
+/* The drivers' time loop on one rank (fdtd1.cu:68-80 with nprocs == 1): `steps` ping-pong
+ * steps, step 0 writes a = f(b), then the roles swap.  On return cube `a`/`b` hold exactly what
+ * the reference's two cubes hold after the same number of steps. */
+int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const fdtdx_program *prog, uint32_t steps,
+                void *stream);
+
+/* Ghost-plane exchange regions (commCubeHalo, stencil.h:639-647): pointer/count of the planes to
+ * SEND to (what = 0) or RECEIVE from (what = 1) the neighbour on `side` (0 = rank-1, 1 = rank+1).
+ * count = M*plane floats, or 0 when there is no neighbour on that side.  Planes are contiguous,
+ * so the region is handed to RCCL send/recv (or hipMemcpyPeer) without packing. */
+int fdtdx_halo_region(fdtdx_ctx *ctx, const char *name, int side, int what, float **ptr, size_t *count);
+
+/* Kernel-selection knobs, for tuning and tests: "zchunks" (z-chunks per sweep launch, 0 = auto),
+ * "variant" (tile-shape index, -1 = auto). */
+int fdtdx_set_option(fdtdx_ctx *ctx, const char *key, int64_t value);
+/* Describes the kernel the last sweep launched (tile shape, grid, LDS), for logs and bench. */
+int fdtdx_last_launch_info(const fdtdx_ctx *ctx, char *buf, size_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDTDX_H */
