@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- cell-update throughput of the sweep hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--variant fdtd4] [--n 512]
+
+A "step" is one time step of the drivers' loop (fdtd1.cu:68-80): one sweep of the whole slab
+plus, on N > 1 GPUs, the ghost-plane exchange with the z neighbours.  Weak scaling: every GPU
+owns an n^3 slab of a (N*n) x n x n grid, as the reference's z-slab split gives (stencil.h:398-412).
+Inputs are the drivers' synthetic fields (fdtd1.cu:21-31 / jacobi.cu:412-417), resident in HBM
+before the timed region.  Rank 0 prints ONE JSON line.
+
+metric   Gcell/s = updated cells x steps / wall seconds (max over ranks), updated cells per
+         step = the interior the reference updates (fdtd1.cu:43-45) summed over all ranks.
+roofline bound = HBM; algorithmic traffic 8 B per cell-update (one fp32 read + one fp32 write);
+         achieved = 8 B x cells per launch / average launch duration, measured here with HIP
+         events on the launch stream; peak 8 TB/s.
+cpu_baseline  the reference's own golden loop compiled from its sources (oracle/_ref/ref_bench,
+         CMakeLists.txt:17 flags) or, where that binary is absent, this repo's restatement
+         (oracle/liboracle.so), timed on this box's host cores on the same grid for a bounded
+         number of steps.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+VARIANTS = {  # name -> (program kind, radius, reference driver)
+    **{f"fdtd{m}": ("star", m, f"fdtd{m}.cu") for m in range(1, 9)},
+    "fdtdspc": ("spc13", 1, "fdtdspc.cu"),
+    "jacobi": ("jacobi7", 1, "jacobi.cu"),
+}
+PEAK_HBM_GBS = 8000.0
+BYTES_PER_UPDATE = 8.0
+
+
+def cpu_baseline(kind, radius, n, budget_s=12.0):
+    """Time the CPU golden loop on the host cores; returns the cpu_baseline object."""
+    kid = {"star": 0, "spc13": 1, "jacobi7": 2}[kind]
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads))
+    if kind == "jacobi7":
+        threads = 1  # jacobi.cu:475-485 is a serial loop in the reference
+    if os.path.exists(exe):
+        def run(steps):
+            out = subprocess.run([exe, str(kid), str(radius), str(n), str(n), str(n), str(steps)], env=env,
+                                 capture_output=True, text=True, timeout=600, check=True).stdout
+            return json.loads(out.strip().splitlines()[-1])
+        probe = run(2)
+        steps = max(2, min(2000, int(budget_s / max(probe["seconds"] / 2, 1e-4))))
+        r = run(steps)
+        return {"value": round(r["gcells_per_s"], 3), "unit": "Gcell/s", "cores": threads if kind != "jacobi7" else 1,
+                "kind": "reference",
+                "sample": f"{steps} steps of the {n}^3 golden loop (g++ -std=c++11 -Ofast -fopenmp), {r['seconds']:.2f} s"}
+    # fall back to this repo's CPU restatement
+    import numpy as np
+    from oracle import cpu
+    if kind == "jacobi7":
+        a = cpu.init_jacobi(n, n, n)
+        b = a.copy()
+    else:
+        a, b = cpu.init_mt(n, n, n)
+    cpu.run(kind, a, b, 1, M=radius, order=cpu.ORDER_GOLDEN)
+    t0 = time.time()
+    steps = 0
+    while time.time() - t0 < budget_s and steps < 2000:
+        cpu.run(kind, a, b, 2, M=radius, order=cpu.ORDER_GOLDEN)
+        steps += 2
+    dt = time.time() - t0
+    cells = float(n - 2 * radius) ** 3 * steps
+    return {"value": round(cells / dt * 1e-9, 3), "unit": "Gcell/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} steps of the {n}^3 loop (oracle/fdtd_oracle.c, gcc -O2 strict IEEE), {dt:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--variant", default="fdtd4", choices=sorted(VARIANTS))
+    ap.add_argument("--n", type=int, default=512, help="slab edge: every GPU owns n planes of n x n cells")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--all-variants", action="store_true", help="also time every other variant (N=1 only)")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from fdtd_amd import make_program
+    from fdtd_amd.slab import HipSlabBackend, SlabRunner
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def time_variant(name, steps, warmup):
+        kind, radius, _ = VARIANTS[name]
+        n = a.n
+        be = HipSlabBackend(n * world, n, n, radius, rank, world, local_rank)
+        be.alloc("p0")
+        be.alloc("p1")
+        if kind == "jacobi7":
+            be.st.initJacobi("p0")
+            be.st.initJacobi("p1")
+        else:
+            be.st.initMt("p0", "p1")
+        prog = make_program(kind, radius=radius)
+        run = SlabRunner(be, radius, prog, rank, world)
+        run.run("p0", "p1", warmup)
+        barrier()
+        stream = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        run.run("p0", "p1", steps)
+        e1.record(stream)
+        barrier()
+        dt = time.perf_counter() - t0
+        ev_ms = e0.elapsed_time(e1)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        cells_rank = float(run.z_hi - run.z_lo) * float(n - 2 * radius) ** 2   # this rank, one step
+        cells_all = (float(n * world - 2 * radius)) * float(n - 2 * radius) ** 2
+        info = be.st.lastLaunchInfo()
+        be.st.close()
+        del be
+        torch.cuda.empty_cache()
+        return dict(dt=dt, ev_ms=ev_ms, cells_rank=cells_rank, cells_all=cells_all, info=info, kind=kind, radius=radius)
+
+    r = time_variant(a.variant, a.steps, a.warmup)
+    value = r["cells_all"] * a.steps / r["dt"] * 1e-9
+    # dominant kernel = the sweep; at N=1 a step is exactly one launch of it
+    launch_s = r["ev_ms"] * 1e-3 / a.steps
+    achieved = BYTES_PER_UPDATE * r["cells_rank"] / launch_s * 1e-9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get(f"{a.variant}_n{a.n}", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    line = {
+        "metric": "cell-updates/sec", "value": round(value, 2), "unit": "Gcell/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(r["dt"] / a.steps * 1e3, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{a.variant}: {VARIANTS[a.variant][0]} radius {r['radius']} sweep "
+                               f"({VARIANTS[a.variant][2]}), {a.n * world}x{a.n}x{a.n} fp32 grid, {a.steps} steps, "
+                               f"z-slabs of {a.n} planes per GPU",
+                   "grid": [a.n * world, a.n, a.n], "radius": r["radius"], "parallelism": f"zslab{world}",
+                   "kernel": r["info"]},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic,
+                     "algorithmic_bytes_per_launch": BYTES_PER_UPDATE * r["cells_rank"],
+                     "launch_us": round(launch_s * 1e6, 2)},
+    }
+    if a.all_variants and world == 1:
+        others = {}
+        for name in sorted(VARIANTS):
+            if name == a.variant:
+                continue
+            o = time_variant(name, min(a.steps, 200), 5)
+            others[name] = round(o["cells_all"] * min(a.steps, 200) / o["dt"] * 1e-9, 1)
+        line["other_variants_gcells"] = others
+    if rank == 0 and world == 1 and not a.no_cpu:
+        try:
+            line["cpu_baseline"] = cpu_baseline(r["kind"], r["radius"], a.n)
+        except Exception as e:  # the GPU number stands on its own
+            line["cpu_baseline"] = {"value": None, "unit": "Gcell/s", "cores": 0, "kind": "reference",
+                                    "sample": f"failed: {e}"}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,125 @@
+"""z-slab time loop with ghost-plane exchange: one process per GPU, torch.distributed P2P.
+
+Replaces the per-step choreography of the reference drivers (fdtd1.cu:68-80) and the halo
+machinery of stencil.h:639-682 / 770-808:
+
+  reference (per step)                          here (per step)
+  ------------------------------------------   ---------------------------------------------
+  backupCubeHaloBackup   D2D 3M planes x2       --  (ghost planes live inside the cube)
+  propagateHalo{Top,Buttom}Backup (M planes)    sweep the M boundary planes next to each face
+  sync; propagate (whole slab, async)           start isend/irecv of those planes (RCCL stream)
+  commCubeHaloBackup     host-blocking MPI      sweep the interior planes (compute stream)
+  sync; restoreCubeHaloBackup D2D x2; sync      wait for the exchange; swap
+
+The boundary planes are written once (not twice as in the reference) and are received
+directly into the neighbour's ghost planes of the ping-pong output cube, so there are no
+staging copies.  torch.distributed's "nccl" backend is RCCL on ROCm: sends and receives run on
+RCCL's own HIP stream, ordered after the boundary sweep and overlapped with the interior sweep.
+The same code runs on CPU tensors over "gloo" (tests), with the sweep supplied by the caller.
+
+Both ping-pong cubes are exchanged every step, which is the decomposition-independent update
+(the pattern of main.cu:151-168, not the single-cube shortcut of fdtd1.cu:70-77).
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import lib as _lib
+from .stencil import Stencil
+
+
+class HipSlabBackend:
+    """Cubes in HBM owned by torch, sweeps by libfdtdx.so on torch's current stream."""
+
+    def __init__(self, Z, Y, X, M, rank, nprocs, device):
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.st = Stencil(Z, Y, X, M, rank=rank, nprocs=nprocs, device=device)
+        self.g = self.st.geometry
+        self.bufs = {}
+
+    def alloc(self, name):
+        t = torch.zeros(int(self.g.cube_elems), dtype=torch.float32, device=self.device)
+        self.bufs[name] = t
+        self.st.attachCube(name, t.data_ptr(), t.numel() * 4)
+        return t
+
+    def planes(self, name, first, count):
+        p = int(self.g.plane)
+        return self.bufs[name][first * p:(first + count) * p]
+
+    def sweep(self, out, inp, program, z_lo, z_hi):
+        if z_hi > z_lo:
+            self.st.propagatePlanes(out, inp, program, z_lo, z_hi, torch.cuda.current_stream().cuda_stream)
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
+
+
+class SlabRunner:
+    """The time loop of one rank.  `backend` provides alloc/planes/sweep/synchronize and `.g`."""
+
+    def __init__(self, backend, M, program, rank, nprocs, group=None):
+        self.b, self.M, self.prog = backend, M, program
+        self.rank, self.nprocs, self.group = rank, nprocs, group
+        g = backend.g
+        self.local = int(g.local_planes)
+        self.has_lo = int(g.ghost_lo) > 0
+        self.has_hi = int(g.ghost_hi) > 0
+        self.radius = program.radius if program.kind == _lib.STAR else 1
+        # planes this rank updates (stencil.h:690)
+        self.z_lo = int(g.ghost_lo) if self.has_lo else self.radius
+        self.z_hi = self.local - int(g.ghost_hi) if self.has_hi else self.local - self.radius
+
+    def _exchange_ops(self, name):
+        """P2P ops moving this cube's boundary planes into the neighbours' ghost planes
+        (commCubeHalo, stencil.h:639-647)."""
+        M, ops = self.M, []
+        if self.has_lo:
+            ops.append(dist.P2POp(dist.isend, self.b.planes(name, M, M), self.rank - 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, self.b.planes(name, 0, M), self.rank - 1, self.group))
+        if self.has_hi:
+            ops.append(dist.P2POp(dist.isend, self.b.planes(name, self.local - 2 * M, M), self.rank + 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, self.b.planes(name, self.local - M, M), self.rank + 1, self.group))
+        return ops
+
+    def step(self, out, inp):
+        """out = f(inp) on the owned planes, then out's ghost planes = neighbours' new boundary planes."""
+        M = self.M
+        lo, hi = self.z_lo, self.z_hi
+        ilo, ihi = lo, hi
+        if self.has_lo:  # the M planes the lower neighbour needs
+            ilo = min(lo + M, hi)
+            self.b.sweep(out, inp, self.prog, lo, ilo)
+        if self.has_hi:
+            ihi = max(hi - M, ilo)
+            self.b.sweep(out, inp, self.prog, ihi, hi)
+        reqs = []
+        if self.nprocs > 1:
+            ops = self._exchange_ops(out)
+            if ops:
+                reqs = dist.batch_isend_irecv(ops)
+        self.b.sweep(out, inp, self.prog, ilo, ihi)
+        for r in reqs:
+            r.wait()
+
+    def run(self, a, b, steps):
+        """`steps` ping-pong steps: step 0 writes a = f(b) (fdtd1.cu:68-80)."""
+        out, inp = a, b
+        for _ in range(steps):
+            self.step(out, inp)
+            out, inp = inp, out
+        return inp, out  # (newest, previous)
+
+
+def gather_cube(backend, name, Z, Y, X, rank, nprocs, group=None):
+    """transferCubeToCPU's cross-rank part (stencil.h:623-636): every rank ends with the full
+    unpadded [Z][Y][X] grid.  HIP backend only."""
+    owned = torch.from_numpy(backend.st.downloadOwned(name))
+    if nprocs == 1:
+        return owned.numpy()
+    parts = [None] * nprocs
+    dist.all_gather_object(parts, owned.numpy(), group=group)
+    import numpy as np
+    return np.concatenate(parts, axis=0)

@@ -1,0 +1,75 @@
+"""Times every compiled tile shape of a sweep at full size on the GPU (tuning aid, not a test).
+
+usage: python tools/tune.py [--kinds star,spc13,jacobi7] [--radii 1,2,..] [--n 512] [--steps 20]
+Prints one line per (kind, radius, variant, zchunks) with Gcell/s; inputs are the drivers'
+mt19937 fields (fdtd1.cu:21-31) generated once per radius.
+"""
+import argparse
+import json
+import sys
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from fdtd_amd import Stencil, make_program, FdtdxError
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kinds", default="star")
+    ap.add_argument("--radii", default="1,2,3,4,5,6,7,8")
+    ap.add_argument("--n", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--zchunks", default="0")
+    ap.add_argument("--out", default="")
+    ap.add_argument("--variants", default="", help="comma list of variant indices (default: all)")
+    a = ap.parse_args()
+    n = a.n
+    stream = torch.cuda.current_stream().cuda_stream
+    results = []
+    for kind in a.kinds.split(","):
+        radii = [int(r) for r in a.radii.split(",")] if kind == "star" else [1]
+        for M in radii:
+            with Stencil(n, n, n, M) as st:
+                st.mallocCube("p0")
+                st.mallocCube("p1")
+                st.initMt("p0", "p1")
+                prog = make_program(kind, radius=M)
+                cells = float(n - 2 * M) ** 3
+                vlist = [int(x) for x in a.variants.split(',')] if a.variants else None
+                v = 0
+                while True:
+                    if vlist is not None:
+                        if not vlist:
+                            break
+                        v = vlist.pop(0)
+                    st.setOption("variant", v)
+                    ok = True
+                    for zc in [int(z) for z in a.zchunks.split(",")]:
+                        st.setOption("zchunks", zc)
+                        try:
+                            st.sweep("p0", "p1", prog, 2, stream)
+                        except FdtdxError:
+                            ok = False
+                            break
+                        torch.cuda.synchronize()
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        st.sweep("p0", "p1", prog, a.steps, stream)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        ms = e0.elapsed_time(e1) / a.steps
+                        gc = cells / ms * 1e-6
+                        info = st.lastLaunchInfo()
+                        print(f"{kind} M={M} v={v} zc={zc}: {ms*1e3:8.1f} us/step {gc:8.1f} Gcell/s  [{info}]", flush=True)
+                        results.append(dict(kind=kind, M=M, variant=v, zchunks=zc, us=ms * 1e3, gcells=gc, info=info))
+                    if not ok:
+                        break
+                    v += 1
+    if a.out:
+        json.dump(results, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
