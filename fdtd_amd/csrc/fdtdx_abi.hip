@@ -89,7 +89,7 @@ extern "C" int fdtdx_decompose(const fdtdx_config *cfg, fdtdx_geometry *out)
                     (unsigned long long)cfg->Z, (unsigned long long)cfg->Y, (unsigned long long)cfg->X);
     uint64_t px = cfg->pitch_x ? cfg->pitch_x : (cfg->X / 32 + 1) * 32;
     if (px % 32 != 0 || px < cfg->X) return fail(FDTDX_ERR_INVALID, "pitch_x %llu must be a multiple of 32 >= X", (unsigned long long)px);
-    if (cfg->Y * px > 0x7fffffffull) return fail(FDTDX_ERR_UNSUPPORTED, "plane of %llu floats exceeds 2^31", (unsigned long long)(cfg->Y * px));
+    if (cfg->Y * px * 4 > 0x7fffffffull) return fail(FDTDX_ERR_UNSUPPORTED, "plane of %llu floats exceeds 2^31 bytes", (unsigned long long)(cfg->Y * px));
     uint64_t off = 0, size = 0;
     for (uint64_t i = 0; i < np; i++) {
         uint64_t s = cfg->Z / np + ((cfg->Z % np) > i ? 1 : 0);  // mpiSize[i]
@@ -351,7 +351,8 @@ static int check_program(const fdtdx_ctx *ctx, const fdtdx_program *prog, int *r
     return FDTDX_OK;
 }
 
-// Default tile shape per radius for rows of about 512 cells; refined by on-device measurement.
+// Default tile shape per radius (quads x thread-rows x rows-per-thread), chosen from on-device
+// timings of every compiled shape on 512^3 grids (tools/tune.py).
 static void default_shape(int kind, int r, int *tq, int *ly, int *ry)
 {
     if (kind == FDTDX_SPC13) {
@@ -359,13 +360,14 @@ static void default_shape(int kind, int r, int *tq, int *ly, int *ry)
         return;
     }
     switch (r) {
-    case 1: *tq = 128, *ly = 8, *ry = 2; break;
-    case 2: *tq = 128, *ly = 8, *ry = 2; break;
-    case 3: *tq = 64, *ly = 16, *ry = 2; break;
-    case 4: *tq = 64, *ly = 16, *ry = 2; break;
+    case 1: *tq = 128, *ly = 8, *ry = 1; break;
+    case 2: *tq = 128, *ly = 8, *ry = 1; break;
+    case 3: *tq = 64, *ly = 16, *ry = 1; break;
+    case 4: *tq = 32, *ly = 16, *ry = 2; break;
     case 5: *tq = 32, *ly = 16, *ry = 2; break;
     case 6: *tq = 32, *ly = 16, *ry = 2; break;
-    default: *tq = 32, *ly = 32, *ry = 1; break;
+    case 7: *tq = 32, *ly = 16, *ry = 1; break;
+    default: *tq = 32, *ly = 16, *ry = 2; break;
     }
 }
 
@@ -394,7 +396,7 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
     memset(p.c, 0, sizeof(p.c));
     memcpy(p.c, prog->coef, 13 * sizeof(float));
 
-    int tq, ly, ry, threads, lds;
+    int tq, ly, ry, threads, lds, pf = 1;
     void (*launch)(const SweepParams &, dim3, hipStream_t) = nullptr;
     int dtq, dly, dry;
     default_shape(prog->kind, r, &dtq, &dly, &dry);
@@ -417,11 +419,12 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
         for (int i = 0; i < num_variants(); i++) {
             const VariantInfo *v = variant(i);
             if (v->M != r || v->order != ord) continue;
-            if (ctx->opt_variant >= 0 ? (idx == ctx->opt_variant) : (!best || (v->tq == dtq && v->ly == dly && v->ry == dry))) best = v;
+            if (ctx->opt_variant >= 0 ? (idx == ctx->opt_variant) : (!best || (v->tq == dtq && v->ly == dly && v->ry == dry && v->pf == 1))) best = v;
             idx++;
         }
         if (!best) return fail(FDTDX_ERR_UNSUPPORTED, "no kernel for radius %d order %u variant %lld", r, prog->order, (long long)ctx->opt_variant);
         tq = best->tq, ly = best->ly, ry = best->ry, threads = best->threads, lds = best->lds_bytes, launch = best->launch;
+        pf = best->pf;
     }
 
     const int nq = (p.nx + 3) / 4;                      // quads that hold logical cells
@@ -430,22 +433,24 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
     const long long nz = (long long)(z_hi - z_lo);
     long long chunks = ctx->opt_zchunks;
     if (chunks <= 0) {
-        // aim for ~8 workgroups per CU over the chip (256 CUs) while keeping the 2r-plane
-        // pipeline fill below ~1/8 of a chunk
+        // one workgroup per CU (256 CUs) measured fastest: every extra z chunk re-reads 2r planes
+        // to fill its queue, so split z only as far as needed to cover the chip, and keep the
+        // fill below ~1/8 of a chunk
         const long long tiles = (long long)gx * gy;
-        chunks = std::max<long long>(1, (2048 + tiles - 1) / tiles);
+        chunks = std::max<long long>(1, (256 + tiles - 1) / tiles);
         const long long min_len = std::max<long long>(16LL * r, 16);
         chunks = std::min(chunks, std::max<long long>(1, nz / min_len));
     }
     chunks = std::max<long long>(1, std::min(chunks, nz));
     p.zchunk = (int)((nz + chunks - 1) / chunks);
     const int gz = (int)((nz + p.zchunk - 1) / p.zchunk);
-    if (gy > 65535 || gz > 65535) return fail(FDTDX_ERR_UNSUPPORTED, "grid too large (%d,%d,%d)", gx, gy, gz);
+    if ((long long)gx * gy * gz > 0x7fffffffLL) return fail(FDTDX_ERR_UNSUPPORTED, "grid too large (%d,%d,%d)", gx, gy, gz);
 
-    launch(p, dim3(gx, gy, gz), (hipStream_t)stream);
+    p.gx = gx, p.gy = gy, p.gz = gz;
+    launch(p, dim3((unsigned)gx * gy * gz), (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
-    snprintf(ctx->last_launch, sizeof(ctx->last_launch), "kind=%u r=%d order=%u tile=%dx%d(quads x rows) threads=%d ry=%d lds=%d grid=%dx%dx%d zchunk=%d",
-             prog->kind, r, prog->order, tq, ly * ry, threads, ry, lds, gx, gy, gz, p.zchunk);
+    snprintf(ctx->last_launch, sizeof(ctx->last_launch), "kind=%u r=%d order=%u tile=%dx%d(quads x rows) threads=%d ry=%d pf=%d lds=%d grid=%dx%dx%d zchunk=%d",
+             prog->kind, r, prog->order, tq, ly * ry, threads, ry, pf, lds, gx, gy, gz, p.zchunk);
     return FDTDX_OK;
 }
 

@@ -27,9 +27,11 @@ __global__ __launch_bounds__(TQ *LY) void spc13_sweep_kernel(const SweepParams p
 
     const int t = threadIdx.x;
     const int tx = t % TQ, ty = t / TQ;
-    const int q0 = blockIdx.x * TQ;
-    const int y0 = 1 + blockIdx.y * CY;
-    const int zs = p.z_lo + blockIdx.z * p.zchunk;
+    int bx, by, bz;
+    logical_tile(p, bx, by, bz);
+    const int q0 = bx * TQ;
+    const int y0 = 1 + by * CY;
+    const int zs = p.z_lo + bz * p.zchunk;
     const int ze = min(zs + p.zchunk, p.z_hi);
     if (zs >= ze) return;
 

@@ -11,12 +11,22 @@
 //     plane is read from HBM exactly once per tile as one coalesced 16-byte-per-lane load.
 //   * x and y neighbours come from the centre plane staged in LDS: every thread publishes its
 //     centre quad, and the tile's halo (M rows above/below, ceil(M/4) quads left/right, no
-//     corners -- a star never reads them) is fetched by extra predicated loads spread over the
-//     workgroup.  The x neighbours of a quad are the aligned quads left/right of it, so shifted
-//     operands are picked by register naming, not by unaligned LDS reads or lane shuffles.
+//     corners -- a star never reads them) is fetched by extra loads spread over the workgroup.
+//     The x neighbours of a quad are the aligned quads left/right of it, so shifted operands are
+//     picked by register naming, not by unaligned LDS reads or lane shuffles.
 //   * LDS is double buffered: one barrier per plane.
-//   * The loads of plane z+M+1 (and of the halo of plane z+1) are issued before the arithmetic of
-//     plane z, so they fly across the barrier and the FMA chain.
+//   * All global traffic goes through raw buffer loads/stores whose per-lane offset is pushed
+//     out of range for lanes that must not touch memory (rows/quads outside the grid, shell
+//     cells): the hardware returns 0 / drops the store.  The z loop therefore has no divergent
+//     branch and a fixed number of memory operations per iteration, so the waits the compiler
+//     places are counted (vmcnt(N)) and the loads of plane z+M+1 stay in flight across the
+//     barrier, the FMA chain and the stores of plane z.
+//   * Quads that straddle the shell in x are stored whole: the shell components carry the
+//     value the output cube already holds there (read once per plane by those lanes only), so
+//     a row needs exactly one store instruction.
+//   * For M <= 4 the z loop is unrolled once per queue slot with rotating slot names, so the
+//     queue advances by renaming instead of register moves, and new planes are loaded straight
+//     into their final slot PF planes ahead of their first use (more bytes in flight per CU).
 #pragma once
 #include "sweep_common.h"
 
@@ -33,54 +43,194 @@ __device__ __forceinline__ float pair_or_chain(float acc, float cp, float vp, fl
     }
 }
 
-template <int M, int TQ, int LY, int RY, int ORDER>
+template <int I>
+struct PhaseTag {
+    static constexpr int value = I;
+};
+template <int PH, int N, class F>
+__device__ __forceinline__ void unroll_phases(F &&f)
+{
+    if constexpr (PH < N) {
+        f(PhaseTag<PH>{});
+        unroll_phases<PH + 1, N>(f);
+    }
+}
+
+constexpr int star_nhk(int M, int TQ, int LY, int RY)
+{
+    return (2 * M * TQ + LY * RY * 2 * ((M + 3) / 4) + TQ * LY - 1) / (TQ * LY);
+}
+
+// Per-thread constants of the march.
+template <int RY, int NHK>
+struct Lane {
+    unsigned goff[RY];    // byte offset of the own quad of row j inside a plane (or OOB)
+    unsigned soff[RY];    // same for the store (OOB unless the row is computed and the quad has interior cells)
+    unsigned eoff[RY];    // byte offset for re-reading the output's shell components (partial quads only)
+    unsigned hgoff[NHK];  // halo quads this thread fetches
+    int hloff[NHK];       // where they go in the LDS image (quad index), -1: none
+    int lown[RY];         // own quad in the LDS image
+    bool m0, m1, m2, m3;  // which cells of the own quad are interior in x
+};
+
+// One plane of the march.  The queue holds planes z-M .. z+M+PF; logical slot k (plane z-M+k)
+// lives in physical slot (k + PH) % QT, so advancing z by one is a renaming.  Slots 2M+1 ..
+// 2M+PF-1 are loads still in flight; the load issued here (plane z+M+PF) takes the slot that
+// plane z-M-1 has just left.
+template <int M, int TQ, int LY, int RY, int ORDER, int PF, int PH>
+__device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], float4 (&eo)[RY],
+                                           float4 (&hv)[star_nhk(M, TQ, LY, RY)], const Lane<RY, star_nhk(M, TQ, LY, RY)> &L,
+                                           float4 *buf, const float *&pn, const float *&pc, float *&po, bool more_n, bool more_c,
+                                           unsigned plane_bytes, const float (&c)[7])
+{
+    constexpr int HQ = (M + 3) / 4;
+    constexpr int LPQ = TQ + 2 * HQ;
+    constexpr int NHK = star_nhk(M, TQ, LY, RY);
+    constexpr int QT = 2 * M + 1 + PF;
+#define QS(k) (((k) + PH) % QT)
+
+    // publish the centre plane + halo
+#pragma unroll
+    for (int j = 0; j < RY; j++) buf[L.lown[j]] = q[j][QS(M)];
+#pragma unroll
+    for (int k = 0; k < NHK; k++)
+        if (L.hloff[k] >= 0) buf[L.hloff[k]] = hv[k];
+
+    // prefetches; where there is no such plane the descriptor is empty and the loads return 0
+    const unsigned nbn = more_n ? plane_bytes : 0u, nbc = more_c ? plane_bytes : 0u;
+    const long long pf = plane_bytes >> 2;
+    const __amdgpu_buffer_rsrc_t rn = make_rsrc(pn, nbn);        // plane z+M+PF
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(pc + pf, nbc);   // halo of plane z+1
+    const __amdgpu_buffer_rsrc_t ron = make_rsrc(po + pf, nbc);  // shell components of output plane z+1
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(po, plane_bytes);
+    float4 eo_cur[RY];
+#pragma unroll
+    for (int j = 0; j < RY; j++) {
+        eo_cur[j] = eo[j];
+        q[j][QS(QT - 1)] = buf_ld4(rn, L.goff[j]);
+    }
+#pragma unroll
+    for (int k = 0; k < NHK; k++) hv[k] = buf_ld4(rc, L.hgoff[k]);
+#pragma unroll
+    for (int j = 0; j < RY; j++) eo[j] = buf_ld4(ron, L.eoff[j]);
+    __syncthreads();
+
+    const float c0 = c[0], cxp = c[1], cxm = c[2], cyp = c[3], cym = c[4], czp = c[5], czm = c[6];
+#pragma unroll
+    for (int j = 0; j < RY; j++) {
+        const float4 *row = buf + L.lown[j];
+        // x window: quads [-HQ .. +HQ] around the own quad, as a flat register array
+        float xs[4 * (2 * HQ + 1)];
+#pragma unroll
+        for (int s = -HQ; s <= HQ; s++) {
+            const float4 v = (s == 0) ? q[j][QS(M)] : row[s];
+            xs[4 * (s + HQ) + 0] = v.x;
+            xs[4 * (s + HQ) + 1] = v.y;
+            xs[4 * (s + HQ) + 2] = v.z;
+            xs[4 * (s + HQ) + 3] = v.w;
+        }
+        constexpr int XB = 4 * HQ;  // index of the own quad's first cell in xs
+        float acc[4];
+        if constexpr (ORDER == ORD_STAR_CHAIN || ORDER == ORD_STAR_GOLDEN) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[i] = c0 * xs[XB + i];
+#pragma unroll
+            for (int r = 1; r <= M; r++) {
+                const float4 yp = row[r * LPQ], ym = row[-r * LPQ];
+                const float4 zp = q[j][QS(M + r)], zm = q[j][QS(M - r)];
+                const float ypv[4] = {yp.x, yp.y, yp.z, yp.w}, ymv[4] = {ym.x, ym.y, ym.z, ym.w};
+                const float zpv[4] = {zp.x, zp.y, zp.z, zp.w}, zmv[4] = {zm.x, zm.y, zm.z, zm.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    acc[i] = pair_or_chain<ORDER>(acc[i], cxp, xs[XB + i + r], cxm, xs[XB + i - r]);
+                    acc[i] = pair_or_chain<ORDER>(acc[i], cyp, ypv[i], cym, ymv[i]);
+                    acc[i] = pair_or_chain<ORDER>(acc[i], czp, zpv[i], czm, zmv[i]);
+                }
+            }
+        } else {
+            // jacobi.cu:31-38 order: ce*E + cw*W + cs*S + cn*N + ct*T + cb*B + cc*C
+            // coefficient slots: c0=cc, cxp=ce, cxm=cw, cyp=cs, cym=cn, czp=ct, czm=cb
+            const float4 yp = row[LPQ], ym = row[-LPQ];
+            const float4 zp = q[j][QS(M + 1)], zm = q[j][QS(M - 1)];
+            const float ypv[4] = {yp.x, yp.y, yp.z, yp.w}, ymv[4] = {ym.x, ym.y, ym.z, ym.w};
+            const float zpv[4] = {zp.x, zp.y, zp.z, zp.w}, zmv[4] = {zm.x, zm.y, zm.z, zm.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if constexpr (ORDER == ORD_JACOBI_GOLDEN) {
+                    acc[i] = cxp * xs[XB + i + 1] + cxm * xs[XB + i - 1] + cyp * ypv[i] + cym * ymv[i] + czp * zpv[i] +
+                             czm * zmv[i] + c0 * xs[XB + i];
+                } else {
+                    float a = cxp * xs[XB + i + 1];
+                    a = __builtin_fmaf(cxm, xs[XB + i - 1], a);
+                    a = __builtin_fmaf(cyp, ypv[i], a);
+                    a = __builtin_fmaf(cym, ymv[i], a);
+                    a = __builtin_fmaf(czp, zpv[i], a);
+                    a = __builtin_fmaf(czm, zmv[i], a);
+                    acc[i] = __builtin_fmaf(c0, xs[XB + i], a);
+                }
+            }
+        }
+        buf_st4(ro, L.soff[j], L.m0 ? acc[0] : eo_cur[j].x, L.m1 ? acc[1] : eo_cur[j].y, L.m2 ? acc[2] : eo_cur[j].z,
+                L.m3 ? acc[3] : eo_cur[j].w);
+    }
+    pn += pf;
+    pc += pf;
+    po += pf;
+#undef QS
+}
+
+template <int M, int TQ, int LY, int RY, int ORDER, int PF>
 __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
 {
-    constexpr int HQ = (M + 3) / 4;                // halo quads on each side in x
-    constexpr int NT = TQ * LY;                    // threads
-    constexpr int CY = LY * RY;                    // computed rows per tile
-    constexpr int LROWS = CY + 2 * M;              // LDS rows (tile + y halo)
-    constexpr int LPQ = TQ + 2 * HQ;               // LDS row pitch in quads (tile + x halo)
-    constexpr int NHY = 2 * M * TQ;                // halo quads above/below
-    constexpr int NHQ = NHY + CY * 2 * HQ;         // + halo quads left/right
-    constexpr int NHK = (NHQ + NT - 1) / NT;       // halo loads per thread
-    constexpr int QN = 2 * M + 1;
+    static_assert(ORDER == ORD_STAR_CHAIN || ORDER == ORD_STAR_GOLDEN || M == 1, "jacobi is radius 1");
+    constexpr int HQ = (M + 3) / 4;           // halo quads on each side in x
+    constexpr int NT = TQ * LY;               // threads
+    constexpr int CY = LY * RY;               // computed rows per tile
+    constexpr int LROWS = CY + 2 * M;         // LDS rows (tile + y halo)
+    constexpr int LPQ = TQ + 2 * HQ;          // LDS row pitch in quads (tile + x halo)
+    constexpr int NHY = 2 * M * TQ;           // halo quads above/below
+    constexpr int NHQ = NHY + CY * 2 * HQ;    // + halo quads left/right
+    constexpr int NHK = star_nhk(M, TQ, LY, RY);
+    static_assert(NHK == (NHQ + NT - 1) / NT, "halo count");
+    constexpr int QT = 2 * M + 1 + PF;        // queue slots
+    constexpr bool ROTATE = (M <= 4);         // unroll the z loop QT times instead of shifting the queue
+    static_assert(ROTATE || PF == 1, "the shifting queue prefetches one plane ahead");
 
     __shared__ float4 lds[2][LROWS * LPQ];
 
     const int t = threadIdx.x;
     const int tx = t % TQ, ty = t / TQ;
-    const int q0 = blockIdx.x * TQ;                // first quad of the tile
-    const int y0 = p.h + blockIdx.y * CY;          // first computed row of the tile
-    const int zs = p.z_lo + blockIdx.z * p.zchunk;
+    int bx, by, bz;
+    logical_tile(p, bx, by, bz);
+    const int q0 = bx * TQ;           // first quad of the tile
+    const int y0 = p.h + by * CY;     // first computed row of the tile
+    const int zs = p.z_lo + bz * p.zchunk;
     const int ze = min(zs + p.zchunk, p.z_hi);
-    if (zs >= ze) return;                          // whole workgroup leaves together
+    if (zs >= ze) return;                     // whole workgroup leaves together
 
+    Lane<RY, NHK> L;
     // ---- own quads -------------------------------------------------------------------------
     const int qx = q0 + tx;
     const bool qok = qx < p.pxq;
-    int goff[RY];       // in-plane offset of the own quad of row j
-    bool rok[RY];       // row exists (may be loaded)
-    bool cok[RY];       // row is computed
+    const int x0 = 4 * qx;
+    L.m0 = (x0 + 0 >= p.h) && (x0 + 0 < p.nx - p.h);
+    L.m1 = (x0 + 1 >= p.h) && (x0 + 1 < p.nx - p.h);
+    L.m2 = (x0 + 2 >= p.h) && (x0 + 2 < p.nx - p.h);
+    L.m3 = (x0 + 3 >= p.h) && (x0 + 3 < p.nx - p.h);
+    const bool mall = L.m0 && L.m1 && L.m2 && L.m3;
+    const bool many = L.m0 || L.m1 || L.m2 || L.m3;
 #pragma unroll
     for (int j = 0; j < RY; j++) {
         const int y = y0 + ty + j * LY;
-        rok[j] = qok && (y < p.ny);
-        cok[j] = qok && (y < p.ny - p.h);
-        goff[j] = y * p.px + 4 * qx;
+        const unsigned off = (unsigned)(y * p.px + 4 * qx) * 4u;
+        const bool rok = qok && (y < p.ny);
+        const bool cok = qok && (y < p.ny - p.h) && many;
+        L.goff[j] = rok ? off : OOB;
+        L.soff[j] = cok ? off : OOB;
+        L.eoff[j] = (cok && !mall) ? off : OOB;
+        L.lown[j] = (M + ty + j * LY) * LPQ + HQ + tx;
     }
-    // per-cell store mask of the own quad: h <= x < nx-h
-    const int x0 = 4 * qx;
-    const bool m0 = (x0 + 0 >= p.h) && (x0 + 0 < p.nx - p.h);
-    const bool m1 = (x0 + 1 >= p.h) && (x0 + 1 < p.nx - p.h);
-    const bool m2 = (x0 + 2 >= p.h) && (x0 + 2 < p.nx - p.h);
-    const bool m3 = (x0 + 3 >= p.h) && (x0 + 3 < p.nx - p.h);
-    const bool mall = m0 && m1 && m2 && m3;
-    const bool many = m0 || m1 || m2 || m3;
-
     // ---- halo quads assigned to this thread --------------------------------------------------
-    int hgoff[NHK], hloff[NHK];
-    bool hok[NHK], hin[NHK];
 #pragma unroll
     for (int k = 0; k < NHK; k++) {
         const int hidx = t + k * NT;
@@ -97,134 +247,75 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
         }
         const int gy = y0 - M + lrow;
         const int gq = q0 - HQ + lcol;
-        hin[k] = (k < NHK - 1) || (hidx < NHQ);
-        hok[k] = hin[k] && (gy < p.ny) && (gq >= 0) && (gq < p.pxq);
-        hgoff[k] = gy * p.px + 4 * gq;
-        hloff[k] = lrow * LPQ + lcol;
+        const bool hin = (k < NHK - 1) || (hidx < NHQ);
+        const bool hok = hin && (gy < p.ny) && (gq >= 0) && (gq < p.pxq);
+        L.hgoff[k] = hok ? (unsigned)(gy * p.px + 4 * gq) * 4u : OOB;
+        L.hloff[k] = hin ? lrow * LPQ + lcol : -1;
     }
 
     // ---- prologue: fill the z queue for centre plane zs ---------------------------------------
+    const unsigned plane_bytes = (unsigned)(p.plane * 4);
     const float *pin = p.in + (long long)(zs - M) * p.plane;  // plane zs-M
-    float4 q[RY][QN];
-    float4 nxt[RY];
+    float4 q[RY][QT];
+    float4 eo[RY];
     float4 hv[NHK];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // rotating: q[k] = plane zs-M+k for k < QT-1, slot QT-1 is loaded by the first step;
+    // shifting: q[k+1] = plane zs-M+k, the loop shifts down by one before each step.
+    constexpr int Q0 = ROTATE ? 0 : 1;
+    const int zlast = p.z_hi + M;  // one past the last plane the sweep may read
 #pragma unroll
     for (int j = 0; j < RY; j++) {
 #pragma unroll
-        for (int k = 1; k < QN; k++) q[j][k] = rok[j] ? ld4(pin + (long long)(k - 1) * p.plane + goff[j]) : zero4;
-        q[j][0] = zero4;
-        nxt[j] = rok[j] ? ld4(pin + (long long)(2 * M) * p.plane + goff[j]) : zero4;
+        for (int k = 0; k < QT - 1; k++)
+            q[j][k + Q0] = buf_ld4(make_rsrc(pin + (long long)k * p.plane, (zs - M + k < zlast) ? plane_bytes : 0u), L.goff[j]);
+        q[j][ROTATE ? QT - 1 : 0] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float *pc = p.in + (long long)zs * p.plane;  // centre plane
-#pragma unroll
-    for (int k = 0; k < NHK; k++) hv[k] = hok[k] ? ld4(pc + hgoff[k]) : zero4;
     float *po = p.out + (long long)zs * p.plane;
-    const float *pn = pc + (long long)(M + 1) * p.plane;  // plane z+M+1 for the next iteration
+#pragma unroll
+    for (int k = 0; k < NHK; k++) hv[k] = buf_ld4(make_rsrc(pc, plane_bytes), L.hgoff[k]);
+#pragma unroll
+    for (int j = 0; j < RY; j++) eo[j] = buf_ld4(make_rsrc(po, plane_bytes), L.eoff[j]);
+    const float *pn = pc + (long long)(M + PF) * p.plane;  // plane z+M+PF, loaded while plane z is computed
+    const int zn_end = min(ze, zlast - (M + PF));          // first z whose plane z+M+PF is not needed/not there
 
-    const float c0 = p.c[0], cxp = p.c[1], cxm = p.c[2], cyp = p.c[3], cym = p.c[4], czp = p.c[5], czm = p.c[6];
+    float c[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) c[i] = p.c[i];
 
-    for (int z = zs; z < ze; z++) {
-        float4 *buf = lds[(z - zs) & 1];
-        // shift the queue, take in plane z+M, publish the centre plane and its halo
-#pragma unroll
-        for (int j = 0; j < RY; j++) {
-#pragma unroll
-            for (int k = 0; k < QN - 1; k++) q[j][k] = q[j][k + 1];
-            q[j][QN - 1] = nxt[j];
-            buf[(M + ty + j * LY) * LPQ + HQ + tx] = q[j][M];
-        }
-#pragma unroll
-        for (int k = 0; k < NHK; k++)
-            if (hin[k]) buf[hloff[k]] = hv[k];
-        // prefetch for the next centre plane
-        if (z + 1 < ze) {
-            pc += p.plane;
-#pragma unroll
-            for (int j = 0; j < RY; j++) nxt[j] = rok[j] ? ld4(pn + goff[j]) : zero4;
-#pragma unroll
-            for (int k = 0; k < NHK; k++) hv[k] = hok[k] ? ld4(pc + hgoff[k]) : zero4;
-            pn += p.plane;
-        }
-        __syncthreads();
-
-#pragma unroll
-        for (int j = 0; j < RY; j++) {
-            if (!(cok[j] && many)) continue;
-            const float4 *row = buf + (M + ty + j * LY) * LPQ + HQ + tx;
-            // x window: quads [-HQ .. +HQ] around the own quad, as a flat register array
-            float xs[4 * (2 * HQ + 1)];
-#pragma unroll
-            for (int s = -HQ; s <= HQ; s++) {
-                const float4 v = (s == 0) ? q[j][M] : row[s];
-                xs[4 * (s + HQ) + 0] = v.x;
-                xs[4 * (s + HQ) + 1] = v.y;
-                xs[4 * (s + HQ) + 2] = v.z;
-                xs[4 * (s + HQ) + 3] = v.w;
-            }
-            constexpr int XB = 4 * HQ;  // index of the own quad's first cell in xs
-            float acc[4];
-            if constexpr (ORDER == ORD_STAR_CHAIN || ORDER == ORD_STAR_GOLDEN) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) acc[i] = c0 * xs[XB + i];
-#pragma unroll
-                for (int r = 1; r <= M; r++) {
-                    const float4 yp = row[r * LPQ], ym = row[-r * LPQ];
-                    const float4 zp = q[j][M + r], zm = q[j][M - r];
-                    const float ypv[4] = {yp.x, yp.y, yp.z, yp.w}, ymv[4] = {ym.x, ym.y, ym.z, ym.w};
-                    const float zpv[4] = {zp.x, zp.y, zp.z, zp.w}, zmv[4] = {zm.x, zm.y, zm.z, zm.w};
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        acc[i] = pair_or_chain<ORDER>(acc[i], cxp, xs[XB + i + r], cxm, xs[XB + i - r]);
-                        acc[i] = pair_or_chain<ORDER>(acc[i], cyp, ypv[i], cym, ymv[i]);
-                        acc[i] = pair_or_chain<ORDER>(acc[i], czp, zpv[i], czm, zmv[i]);
-                    }
+    if constexpr (ROTATE) {
+        int z = zs;
+        int par = 0;
+        while (z < ze) {
+            unroll_phases<0, QT>([&](auto ph) {
+                if (z < ze) {
+                    plane_step<M, TQ, LY, RY, ORDER, PF, decltype(ph)::value>(q, eo, hv, L, lds[par], pn, pc, po, z < zn_end,
+                                                                            z + 1 < ze, plane_bytes, c);
+                    par ^= 1;
+                    z++;
                 }
-            } else {
-                // jacobi.cu:31-38 order: ce*E + cw*W + cs*S + cn*N + ct*T + cb*B + cc*C
-                // coefficient slots: c0=cc, cxp=ce, cxm=cw, cyp=cs, cym=cn, czp=ct, czm=cb
-                static_assert(ORDER == ORD_STAR_CHAIN || ORDER == ORD_STAR_GOLDEN || M == 1, "jacobi is radius 1");
-                const float4 yp = row[LPQ], ym = row[-LPQ];
-                const float4 zp = q[j][M + 1], zm = q[j][M - 1];
-                const float ypv[4] = {yp.x, yp.y, yp.z, yp.w}, ymv[4] = {ym.x, ym.y, ym.z, ym.w};
-                const float zpv[4] = {zp.x, zp.y, zp.z, zp.w}, zmv[4] = {zm.x, zm.y, zm.z, zm.w};
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    if constexpr (ORDER == ORD_JACOBI_GOLDEN) {
-                        acc[i] = cxp * xs[XB + i + 1] + cxm * xs[XB + i - 1] + cyp * ypv[i] + cym * ymv[i] +
-                                 czp * zpv[i] + czm * zmv[i] + c0 * xs[XB + i];
-                    } else {
-                        float a = cxp * xs[XB + i + 1];
-                        a = __builtin_fmaf(cxm, xs[XB + i - 1], a);
-                        a = __builtin_fmaf(cyp, ypv[i], a);
-                        a = __builtin_fmaf(cym, ymv[i], a);
-                        a = __builtin_fmaf(czp, zpv[i], a);
-                        a = __builtin_fmaf(czm, zmv[i], a);
-                        acc[i] = __builtin_fmaf(c0, xs[XB + i], a);
-                    }
-                }
-            }
-            float *o = po + goff[j];
-            if (mall) {
-                *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            } else {
-                if (m0) o[0] = acc[0];
-                if (m1) o[1] = acc[1];
-                if (m2) o[2] = acc[2];
-                if (m3) o[3] = acc[3];
-            }
+            });
         }
-        po += p.plane;
+    } else {
+        for (int z = zs; z < ze; z++) {
+#pragma unroll
+            for (int j = 0; j < RY; j++) {
+#pragma unroll
+                for (int k = 0; k < QT - 1; k++) q[j][k] = q[j][k + 1];
+            }
+            plane_step<M, TQ, LY, RY, ORDER, PF, 0>(q, eo, hv, L, lds[(z - zs) & 1], pn, pc, po, z < zn_end, z + 1 < ze,
+                                                    plane_bytes, c);
+        }
     }
 }
 
-template <int M, int TQ, int LY, int RY, int ORDER>
+template <int M, int TQ, int LY, int RY, int ORDER, int PF>
 void star_launch(const SweepParams &p, dim3 grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((star_sweep_kernel<M, TQ, LY, RY, ORDER>), grid, dim3(TQ * LY), 0, s, p);
+    hipLaunchKernelGGL((star_sweep_kernel<M, TQ, LY, RY, ORDER, PF>), grid, dim3(TQ * LY), 0, s, p);
 }
 
-template <int M, int TQ, int LY, int RY, int ORDER>
+template <int M, int TQ, int LY, int RY, int ORDER, int PF>
 struct StarRegistrar {
     StarRegistrar()
     {
@@ -235,14 +326,16 @@ struct StarRegistrar {
         v.tq = TQ;
         v.ly = LY;
         v.ry = RY;
+        v.pf = PF;
         v.threads = TQ * LY;
         v.lds_bytes = 2 * (LY * RY + 2 * M) * (TQ + 2 * HQ) * 16;
-        v.launch = &star_launch<M, TQ, LY, RY, ORDER>;
+        v.launch = &star_launch<M, TQ, LY, RY, ORDER, PF>;
         register_variant(v);
     }
 };
 
-#define FDTDX_STAR_VARIANT(M, TQ, LY, RY, ORDER) \
-    static ::fdtdx::StarRegistrar<M, TQ, LY, RY, ORDER> reg_##M##_##TQ##_##LY##_##RY##_##ORDER;
+#define FDTDX_STAR_VARIANT_PF(M, TQ, LY, RY, ORDER, PF) \
+    static ::fdtdx::StarRegistrar<M, TQ, LY, RY, ORDER, PF> reg_##M##_##TQ##_##LY##_##RY##_##ORDER##_##PF;
+#define FDTDX_STAR_VARIANT(M, TQ, LY, RY, ORDER) FDTDX_STAR_VARIANT_PF(M, TQ, LY, RY, ORDER, 1)
 
 }  // namespace fdtdx

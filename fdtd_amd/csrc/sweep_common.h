@@ -23,7 +23,8 @@ struct SweepParams {
     int nx, ny;       // logical extents of a plane
     int h;            // shell width in x and y that is never written (= radius)
     int z_lo, z_hi;   // local planes [z_lo, z_hi) to update
-    int zchunk;       // planes marched by one workgroup (blockIdx.z selects the chunk)
+    int zchunk;       // planes marched by one workgroup
+    int gx, gy, gz;   // logical grid of tiles: x tiles, y tiles, z chunks (launched as gx*gy*gz blocks in 1-D)
     float c[13];
 };
 
@@ -34,12 +35,58 @@ struct VariantInfo {
     int tq;     // computed quads (float4) per tile row
     int ly;     // thread rows
     int ry;     // rows per thread
+    int pf;     // planes prefetched ahead of the queue
     int threads;
     int lds_bytes;
     void (*launch)(const SweepParams &, dim3 grid, hipStream_t);
 };
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+// Raw buffer access: a 128-bit descriptor (base, byte count) in scalar registers plus a 32-bit
+// per-lane byte offset.  An offset at or beyond the byte count is out of range: the load returns
+// zeros and the store is dropped, which is how lanes are masked without branches.
+// the builtins traffic in GCC-style vectors; whole-vector bit casts only (a __builtin_bit_cast of
+// a single vector ELEMENT reads element 0 whichever index is written)
+typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
+typedef float f32x4 __attribute__((__vector_size__(16)));
+constexpr unsigned OOB = 0x80000000u;  // beyond any plane (planes are limited to 2^31-1 bytes)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+    return make_float4(f[0], f[1], f[2], f[3]);
+}
+__device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned voff, float a, float b, float c, float d)
+{
+    f32x4 f;
+    f[0] = a;
+    f[1] = b;
+    f[2] = c;
+    f[3] = d;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f), r, voff, 0, 0);
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (each with a private L2): hardware block b and
+// b+8 share an L2.  Remap so that each XCD owns a contiguous run of logical tiles -- tiles that
+// are neighbours in y (and x) then fetch each other's halo rows from the same L2.  Bijective for
+// any block count.  Placement only affects speed, never results.
+__device__ __forceinline__ void logical_tile(const SweepParams &p, int &bx, int &by, int &bz)
+{
+    const int nb = p.gx * p.gy * p.gz;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int qn = nb >> 3, rn = nb & 7;
+    const int lb = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
+    bx = lb % p.gx;
+    const int t = lb / p.gx;
+    by = t % p.gy;
+    bz = t / p.gy;
+}
 
 // Registry, filled by the per-radius translation units.
 int num_variants();

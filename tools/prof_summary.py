@@ -1,0 +1,34 @@
+"""Summarise a tools/prof.sh output directory: per-kernel time and PMC means (per launch)."""
+import csv
+import glob
+import collections
+import sys
+import json
+
+d = sys.argv[1]
+pat = sys.argv[2] if len(sys.argv) > 2 else "sweep"
+out = {}
+for f in glob.glob(f"{d}/trace/*/*_kernel_stats.csv"):
+    for r in csv.DictReader(open(f)):
+        if pat in r["Name"]:
+            out["kernel"] = r["Name"]
+            out["calls"] = int(r["Calls"])
+            out["avg_us"] = float(r["AverageNs"]) / 1e3
+for f in glob.glob(f"{d}/pmc_*/*/*_counter_collection.csv"):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if pat in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            out["vgpr"] = int(r["VGPR_Count"]); out["sgpr"] = int(r["SGPR_Count"]); out["lds"] = int(r["LDS_Block_Size"])
+            out["scratch"] = int(r["Scratch_Size"])
+    for k, v in agg.items():
+        out[k] = sum(v) / len(v)
+if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
+    # FETCH_SIZE/WRITE_SIZE are in KiB-like units of 1024 B; on gfx950 FETCH_SIZE tallies the 128-B
+    # requests of wide (16 B/lane) streaming reads at 64 B, so the read side is doubled.
+    out["read_bytes_corrected"] = out["FETCH_SIZE"] * 1024 * 2
+    out["write_bytes"] = out["WRITE_SIZE"] * 1024
+    out["hbm_bytes_per_launch"] = out["read_bytes_corrected"] + out["write_bytes"]
+    if "avg_us" in out:
+        out["fabric_TBps"] = out["hbm_bytes_per_launch"] / out["avg_us"] * 1e-6
+print(json.dumps(out, indent=1))
