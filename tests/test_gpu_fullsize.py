@@ -1,0 +1,152 @@
+"""BASELINE-size checks (512^3) of the HIP sweeps.
+
+  * direct bit-exact comparison with the CPU oracle for a few steps (the oracle finishes a
+    512^3 step in well under a second per radius);
+  * size-independent properties: exact linearity under power-of-two scaling, and
+    decomposition invariance (one slab vs two z-slabs exchanging ghost planes on the same GPU);
+  * the 1000-step value classes: with U[0,1) inputs the interiors of radius 1..3 underflow to
+    zero/denormal and radius 5..8 overflow to inf long before step 1000 (gain per step is
+    0.01+0.27*M); only the classes are compared there.
+"""
+import numpy as np
+import pytest
+import torch
+
+from fdtd_amd import Stencil, make_program
+from fdtd_amd.slab import HipSlabBackend, SlabRunner
+
+pytestmark = pytest.mark.gpu
+N = 512
+
+
+def gpu_run(kind, M, a, b, steps):
+    Z, Y, X = a.shape
+    with Stencil(Z, Y, X, M) as st:
+        st.mallocCube("p0")
+        st.mallocCube("p1")
+        st.transferCubeToGPU("p0", a)
+        st.transferCubeToGPU("p1", b)
+        st.sweep("p0", "p1", make_program(kind, radius=M), steps)
+        st.sync()
+        ga, gb = np.empty_like(a), np.empty_like(b)
+        st.transferCubeToCPU(ga, "p0")
+        st.transferCubeToCPU(gb, "p1")
+    return ga, gb
+
+
+@pytest.mark.parametrize("kind,M,steps", [("star", 1, 3), ("star", 4, 2), ("star", 8, 2), ("spc13", 1, 2), ("jacobi7", 1, 3)])
+def test_fullsize_vs_oracle(oracle_cpu, kind, M, steps):
+    if kind == "jacobi7":
+        a = oracle_cpu.init_jacobi(N, N, N)
+        b = a.copy()
+    else:
+        a, b = oracle_cpu.init_mt(N, N, N)
+    ga, gb = gpu_run(kind, M, a, b, steps)
+    oracle_cpu.run(kind, a, b, steps, M=M, order=oracle_cpu.ORDER_CHAIN)
+    assert np.array_equal(ga.view(np.uint32), a.view(np.uint32))
+    assert np.array_equal(gb.view(np.uint32), b.view(np.uint32))
+
+
+def test_device_init_matches_reference_init(oracle_cpu):
+    """fdtdx_init_mt reproduces fdtd1.cu:21-31 (checked through the oracle's pinned generator)."""
+    Z, Y, X = 40, 64, 100
+    a, b = oracle_cpu.init_mt(Z, Y, X)
+    with Stencil(Z, Y, X, 2) as st:
+        st.mallocCube("p0")
+        st.mallocCube("p1")
+        st.initMt("p0", "p1")
+        ga, gb = np.empty_like(a), np.empty_like(b)
+        st.transferCubeToCPU(ga, "p0")
+        st.transferCubeToCPU(gb, "p1")
+    assert np.array_equal(ga, a) and np.array_equal(gb, b)
+
+
+@pytest.mark.parametrize("M", [2, 4])
+def test_linearity_under_power_of_two_scaling(M):
+    """f(4*u) == 4*f(u) bit for bit: the update is linear and scaling by 4 is exact in fp32."""
+    outs = []
+    for scale in (1.0, 4.0):
+        with Stencil(N, N, N, M) as st:
+            st.mallocCube("p0")
+            st.mallocCube("p1")
+            st.initMt("p0", "p1")
+            if scale != 1.0:
+                for name in ("p0", "p1"):
+                    # scale in place on the device through a torch view of the cube
+                    torch_view(st.getCube(name), int(st.geometry.cube_elems)).mul_(scale)
+            st.sweep("p0", "p1", make_program("star", radius=M), 6)
+            st.sync()
+            outs.append((torch_view(st.getCube("p0"), int(st.geometry.cube_elems)).clone(),
+                         torch_view(st.getCube("p1"), int(st.geometry.cube_elems)).clone()))
+    for u, v in zip(outs[0], outs[1]):
+        assert torch.equal(u * 4.0, v)
+
+
+class _CAI:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+def torch_view(ptr, n):
+    """Zero-copy torch tensor over device memory owned by the library."""
+    return torch.as_tensor(_CAI(ptr, n), device="cuda")
+
+
+@pytest.mark.parametrize("kind,M", [("star", 1), ("star", 4), ("star", 8), ("spc13", 1)])
+def test_two_slabs_equal_one(kind, M):
+    """Decomposition invariance at full size: ranks 0 and 1 of a 2-way z split run in this one
+    process on the same GPU; their ghost planes are exchanged by device copies between the
+    regions fdtdx_halo_region names.  The gathered result equals the single-slab run bit for bit."""
+    Z, Y, X, steps = 256, N, N, 5
+    prog = make_program(kind, radius=M)
+    with Stencil(Z, Y, X, M) as st:
+        st.mallocCube("p0")
+        st.mallocCube("p1")
+        st.initMt("p0", "p1")
+        st.sweep("p0", "p1", prog, steps)
+        st.sync()
+        ref0, ref1 = np.empty((Z, Y, X), np.float32), np.empty((Z, Y, X), np.float32)
+        st.transferCubeToCPU(ref0, "p0")
+        st.transferCubeToCPU(ref1, "p1")
+    bes = [HipSlabBackend(Z, Y, X, M, r, 2, 0) for r in range(2)]
+    for be in bes:
+        be.alloc("p0")
+        be.alloc("p1")
+        be.st.initMt("p0", "p1")
+    runs = [SlabRunner(be, M, prog, r, 1) for r, be in enumerate(bes)]  # nprocs=1: no torch.distributed ops
+    for r, run in enumerate(runs):  # ...but keep the neighbour flags of the real 2-way split
+        run.has_lo, run.has_hi = r == 1, r == 0
+    out, inp = "p0", "p1"
+    for _ in range(steps):
+        for run in runs:
+            run.step(out, inp)
+        # rank 0's last M owned planes -> rank 1's low ghosts, rank 1's first M owned -> rank 0's high ghosts
+        l0, l1 = runs[0].local, runs[1].local
+        bes[1].planes(out, 0, M).copy_(bes[0].planes(out, l0 - 2 * M, M))
+        bes[0].planes(out, l0 - M, M).copy_(bes[1].planes(out, M, M))
+        out, inp = inp, out
+    torch.cuda.synchronize()
+    got0 = np.concatenate([be.st.downloadOwned("p0") for be in bes], axis=0)
+    got1 = np.concatenate([be.st.downloadOwned("p1") for be in bes], axis=0)
+    assert np.array_equal(got0.view(np.uint32), ref0.view(np.uint32))
+    assert np.array_equal(got1.view(np.uint32), ref1.view(np.uint32))
+
+
+@pytest.mark.parametrize("M", [1, 4, 8])
+def test_thousand_step_value_classes(oracle_cpu, M):
+    """BASELINE step count on a reduced grid the oracle can follow: identical zero / denormal /
+    normal / inf / nan classes everywhere, and identical bits (same arithmetic, same order)."""
+    Z, Y, X = 40, 48, 72
+    a, b = oracle_cpu.init_mt(Z, Y, X)
+    ga, gb = gpu_run("star", M, a, b, 1000)
+    with np.errstate(all="ignore"):
+        oracle_cpu.run("star", a, b, 1000, M=M, order=oracle_cpu.ORDER_CHAIN)
+
+    def classes(x):
+        ax = np.abs(x)
+        tiny = np.finfo(np.float32).tiny
+        return np.select([np.isnan(x), np.isinf(x), ax == 0, ax < tiny], [4, 3, 0, 1], 2)
+
+    assert np.array_equal(classes(ga), classes(a)) and np.array_equal(classes(gb), classes(b))
+    fin = np.isfinite(a)
+    assert np.array_equal(ga[fin].view(np.uint32), a[fin].view(np.uint32))

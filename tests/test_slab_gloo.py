@@ -1,0 +1,135 @@
+"""Multi-rank z-slab time loop on CPU: world_size 2 and 3 over gloo.
+
+The decomposition (fdtdx_decompose, stencil.h:398-412) and the per-step choreography
+(fdtd_amd/slab.py: boundary planes, exchange, interior) are the product code under test; the
+per-plane arithmetic is supplied by the CPU oracle through a test-only backend, because there is
+no GPU here.  The result must be bit-identical to the undecomposed update
+(decomposition invariance), for every rank count.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from fdtd_amd import lib, make_program
+from fdtd_amd.slab import SlabRunner
+
+
+class OracleSlabBackend:
+    """Padded CPU cubes laid out exactly like the device cubes; sweeps done by the oracle."""
+
+    def __init__(self, cpu, Z, Y, X, M, rank, nprocs):
+        self.cpu, self.Y, self.X, self.M = cpu, Y, X, M
+        self.g = lib.decompose(Z, Y, X, M, rank, nprocs)
+        self.bufs = {}
+
+    def alloc(self, name):
+        t = torch.zeros(int(self.g.cube_elems), dtype=torch.float32)
+        self.bufs[name] = t
+        return t
+
+    def view3(self, name):
+        return self.bufs[name].numpy().reshape(int(self.g.local_planes), self.Y, int(self.g.pitch_x))
+
+    def upload_local(self, name, arr):
+        self.view3(name)[:, :, :self.X] = arr
+
+    def planes(self, name, first, count):
+        p = int(self.g.plane)
+        return self.bufs[name][first * p:(first + count) * p]
+
+    def sweep(self, out, inp, program, z_lo, z_hi):
+        if z_hi <= z_lo:
+            return
+        kind = {lib.STAR: "star", lib.SPC13: "spc13", lib.JACOBI7: "jacobi7"}[program.kind]
+        src = np.ascontiguousarray(self.view3(inp)[:, :, :self.X])
+        dst = np.ascontiguousarray(self.view3(out)[:, :, :self.X])
+        self.cpu.step(kind, dst, src, M=program.radius, order=self.cpu.ORDER_CHAIN, z_lo=z_lo, z_hi=z_hi)
+        self.view3(out)[z_lo:z_hi, :, :self.X] = dst[z_lo:z_hi]
+
+    def synchronize(self):
+        pass
+
+
+def _worker(rank, world, port, kind, M, shape, steps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import cpu
+    Z, Y, X = shape
+    if kind == "jacobi7":
+        a = cpu.init_jacobi(Z, Y, X)
+        b = a.copy()
+    else:
+        a, b = cpu.init_mt(Z, Y, X)
+    be = OracleSlabBackend(cpu, Z, Y, X, M, rank, world)
+    g = be.g
+    lo, n = int(g.first_global), int(g.local_planes)
+    be.alloc("p0")
+    be.alloc("p1")
+    be.upload_local("p0", a[lo:lo + n])
+    be.upload_local("p1", b[lo:lo + n])
+    run = SlabRunner(be, M, make_program(kind, radius=M), rank, world)
+    run.run("p0", "p1", steps)
+    o0, o1 = int(g.ghost_lo), int(g.ghost_lo) + int(g.owned_planes)
+    q.put((rank, int(g.owned_begin), be.view3("p0")[o0:o1, :, :X].copy(), be.view3("p1")[o0:o1, :, :X].copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,kind,M,shape,steps", [
+    (2, "star", 1, (14, 9, 11), 5),
+    (2, "star", 3, (20, 11, 13), 4),
+    (3, "star", 2, (17, 9, 10), 6),   # uneven split: 6,6,5 planes
+    (2, "spc13", 1, (12, 8, 9), 5),
+    (2, "jacobi7", 1, (10, 9, 12), 4),
+])
+def test_decomposition_invariance(oracle_cpu, world, kind, M, shape, steps):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, M, shape, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    parts = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    Z, Y, X = shape
+    got0, got1 = np.zeros(shape, np.float32), np.zeros(shape, np.float32)
+    for rank, begin, p0, p1 in parts:
+        got0[begin:begin + p0.shape[0]] = p0
+        got1[begin:begin + p1.shape[0]] = p1
+    if kind == "jacobi7":
+        a = oracle_cpu.init_jacobi(Z, Y, X)
+        b = a.copy()
+    else:
+        a, b = oracle_cpu.init_mt(Z, Y, X)
+    oracle_cpu.run(kind, a, b, steps, M=M, order=oracle_cpu.ORDER_CHAIN)
+    assert np.array_equal(got0.view(np.uint32), a.view(np.uint32))
+    assert np.array_equal(got1.view(np.uint32), b.view(np.uint32))
+
+
+def test_decompose_matches_reference_formulas():
+    # stencil.h:398-412 for Z=512, M=4 on 3 ranks: mpiSize = 171,171,170
+    sizes, offs = [171, 171, 170], [0, 171, 342]
+    for r in range(3):
+        g = lib.decompose(512, 512, 512, 4, r, 3)
+        assert g.owned_planes == sizes[r] and g.owned_begin == offs[r]
+        assert g.local_planes == sizes[r] + 8 - (4 if r == 0 else 0) - (4 if r == 2 else 0)   # size2 / plane
+        assert g.first_global == offs[r] - (0 if r == 0 else 4)                               # off2 / plane
+        assert g.pitch_x == 544 and g.plane == 512 * 544
+    with pytest.raises(lib.FdtdxError):
+        lib.decompose(16, 32, 32, 4, 0, 2)   # 8 planes per slab is not > 2M (stencil.h:403)
