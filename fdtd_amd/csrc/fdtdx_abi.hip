@@ -356,7 +356,7 @@ static int check_program(const fdtdx_ctx *ctx, const fdtdx_program *prog, int *r
 static void default_shape(int kind, int r, int *tq, int *ly, int *ry)
 {
     if (kind == FDTDX_SPC13) {
-        *tq = 64, *ly = 8, *ry = 2;
+        *tq = 64, *ly = 4, *ry = 2;
         return;
     }
     switch (r) {
@@ -438,6 +438,7 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
         // fill below ~1/8 of a chunk
         const long long tiles = (long long)gx * gy;
         chunks = std::max<long long>(1, (256 + tiles - 1) / tiles);
+        if (threads <= 256) chunks *= 2;  // small workgroups: two per CU
         const long long min_len = std::max<long long>(16LL * r, 16);
         chunks = std::min(chunks, std::max<long long>(1, nz / min_len));
     }

@@ -5,7 +5,9 @@
 // INCLUDING corners, because the stencil has in-plane and cross-plane diagonals) in a ring of
 // four LDS plane images; each plane is read from HBM once per tile with coalesced 16-byte loads
 // and every neighbour, diagonal or not, is an LDS read.  Four ring slots let the loads of
-// plane z+2 land while plane z is being computed with a single barrier per plane.
+// plane z+2 land while plane z is being computed with a single barrier per plane.  Global traffic
+// uses raw buffer loads/stores with out-of-range offsets as lane masks (no divergent branches in
+// the z loop, counted waits), exactly as in star_kernel.h.
 #pragma once
 #include "sweep_common.h"
 
@@ -37,15 +39,6 @@ __global__ __launch_bounds__(TQ *LY) void spc13_sweep_kernel(const SweepParams p
 
     const int qx = q0 + tx;
     const bool qok = qx < p.pxq;
-    int goff[RY];
-    bool rok[RY], cok[RY];
-#pragma unroll
-    for (int j = 0; j < RY; j++) {
-        const int y = y0 + ty + j * LY;
-        rok[j] = qok && (y < p.ny);
-        cok[j] = qok && (y < p.ny - 1);
-        goff[j] = y * p.px + 4 * qx;
-    }
     const int x0 = 4 * qx;
     const bool m0 = (x0 + 0 >= 1) && (x0 + 0 < p.nx - 1);
     const bool m1 = (x0 + 1 >= 1) && (x0 + 1 < p.nx - 1);
@@ -53,9 +46,22 @@ __global__ __launch_bounds__(TQ *LY) void spc13_sweep_kernel(const SweepParams p
     const bool m3 = (x0 + 3 >= 1) && (x0 + 3 < p.nx - 1);
     const bool mall = m0 && m1 && m2 && m3;
     const bool many = m0 || m1 || m2 || m3;
-
-    int hgoff[NHK], hloff[NHK];
-    bool hok[NHK], hin[NHK];
+    // per-lane byte offsets inside a plane; OOB masks the lane (load returns 0, store is dropped)
+    unsigned goff[RY], soff[RY], eoff[RY];
+    int ownl[RY];
+#pragma unroll
+    for (int j = 0; j < RY; j++) {
+        const int y = y0 + ty + j * LY;
+        const unsigned off = (unsigned)(y * p.px + 4 * qx) * 4u;
+        const bool rok = qok && (y < p.ny);
+        const bool cok = qok && (y < p.ny - 1) && many;
+        goff[j] = rok ? off : OOB;
+        soff[j] = cok ? off : OOB;
+        eoff[j] = (cok && !mall) ? off : OOB;
+        ownl[j] = (1 + ty + j * LY) * LPQ + 1 + tx;
+    }
+    unsigned hgoff[NHK];
+    int hloff[NHK];
 #pragma unroll
     for (int k = 0; k < NHK; k++) {
         const int hidx = t + k * NT;
@@ -71,34 +77,38 @@ __global__ __launch_bounds__(TQ *LY) void spc13_sweep_kernel(const SweepParams p
         }
         const int gy = y0 - 1 + lrow;
         const int gq = q0 - 1 + lcol;
-        hin[k] = (k < NHK - 1) || (hidx < NHQ);
-        hok[k] = hin[k] && (gy < p.ny) && (gq >= 0) && (gq < p.pxq);
-        hgoff[k] = gy * p.px + 4 * gq;
-        hloff[k] = lrow * LPQ + lcol;
+        const bool hin = (k < NHK - 1) || (hidx < NHQ);
+        const bool hok = hin && (gy < p.ny) && (gq >= 0) && (gq < p.pxq);
+        hgoff[k] = hok ? (unsigned)(gy * p.px + 4 * gq) * 4u : OOB;
+        hloff[k] = hin ? lrow * LPQ + lcol : -1;
     }
-    int ownl[RY];
-#pragma unroll
-    for (int j = 0; j < RY; j++) ownl[j] = (1 + ty + j * LY) * LPQ + 1 + tx;
 
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned plane_bytes = (unsigned)(p.plane * 4);
     // prologue: planes zs-1 and zs straight into their ring slots, plane zs+1 into registers
     const float *pl = p.in + (long long)(zs - 1) * p.plane;
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         float4 *slot = ring + ((zs - 1 + s) & 3) * SLOT;
+        const __amdgpu_buffer_rsrc_t r = make_rsrc(pl, plane_bytes);
 #pragma unroll
-        for (int j = 0; j < RY; j++) slot[ownl[j]] = rok[j] ? ld4(pl + goff[j]) : zero4;
+        for (int j = 0; j < RY; j++) slot[ownl[j]] = buf_ld4(r, goff[j]);
 #pragma unroll
         for (int k = 0; k < NHK; k++)
-            if (hin[k]) slot[hloff[k]] = hok[k] ? ld4(pl + hgoff[k]) : zero4;
+            if (hloff[k] >= 0) slot[hloff[k]] = buf_ld4(r, hgoff[k]);
         pl += p.plane;
     }
-    float4 nxt[RY], hv[NHK];
-#pragma unroll
-    for (int j = 0; j < RY; j++) nxt[j] = rok[j] ? ld4(pl + goff[j]) : zero4;
-#pragma unroll
-    for (int k = 0; k < NHK; k++) hv[k] = hok[k] ? ld4(pl + hgoff[k]) : zero4;
+    float4 nxt[RY], hv[NHK], eo[RY];
     float *po = p.out + (long long)zs * p.plane;
+    {
+        const __amdgpu_buffer_rsrc_t r = make_rsrc(pl, plane_bytes);
+#pragma unroll
+        for (int j = 0; j < RY; j++) nxt[j] = buf_ld4(r, goff[j]);
+#pragma unroll
+        for (int k = 0; k < NHK; k++) hv[k] = buf_ld4(r, hgoff[k]);
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc(po, plane_bytes);
+#pragma unroll
+        for (int j = 0; j < RY; j++) eo[j] = buf_ld4(ro, eoff[j]);
+    }
 
     float c[13];
 #pragma unroll
@@ -110,21 +120,30 @@ __global__ __launch_bounds__(TQ *LY) void spc13_sweep_kernel(const SweepParams p
         for (int j = 0; j < RY; j++) sp[ownl[j]] = nxt[j];
 #pragma unroll
         for (int k = 0; k < NHK; k++)
-            if (hin[k]) sp[hloff[k]] = hv[k];
-        if (z + 1 < ze) {
-            pl += p.plane;
+            if (hloff[k] >= 0) sp[hloff[k]] = hv[k];
+        // prefetch plane z+2 and the output's shell components of plane z+1; empty descriptors
+        // (all lanes out of range) when the chunk ends
+        const unsigned nb = (z + 1 < ze) ? plane_bytes : 0u;
+        pl += p.plane;
+        const __amdgpu_buffer_rsrc_t rn = make_rsrc(pl, nb);
+        const __amdgpu_buffer_rsrc_t ron = make_rsrc(po + p.plane, nb);
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc(po, plane_bytes);
+        float4 eo_cur[RY];
 #pragma unroll
-            for (int j = 0; j < RY; j++) nxt[j] = rok[j] ? ld4(pl + goff[j]) : zero4;
-#pragma unroll
-            for (int k = 0; k < NHK; k++) hv[k] = hok[k] ? ld4(pl + hgoff[k]) : zero4;
+        for (int j = 0; j < RY; j++) {
+            eo_cur[j] = eo[j];
+            nxt[j] = buf_ld4(rn, goff[j]);
         }
+#pragma unroll
+        for (int k = 0; k < NHK; k++) hv[k] = buf_ld4(rn, hgoff[k]);
+#pragma unroll
+        for (int j = 0; j < RY; j++) eo[j] = buf_ld4(ron, eoff[j]);
         __syncthreads();
 
         const float4 *s0 = ring + (z & 3) * SLOT;
         const float4 *sm = ring + ((z - 1) & 3) * SLOT;
 #pragma unroll
         for (int j = 0; j < RY; j++) {
-            if (!(cok[j] && many)) continue;
             const int o = ownl[j];
             const float4 C = s0[o];
             const float Lw = reinterpret_cast<const float *>(s0 + o - 1)[3];
@@ -171,15 +190,8 @@ __global__ __launch_bounds__(TQ *LY) void spc13_sweep_kernel(const SweepParams p
                 }
                 acc[i] = a;
             }
-            float *op = po + goff[j];
-            if (mall) {
-                *reinterpret_cast<float4 *>(op) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            } else {
-                if (m0) op[0] = acc[0];
-                if (m1) op[1] = acc[1];
-                if (m2) op[2] = acc[2];
-                if (m3) op[3] = acc[3];
-            }
+            buf_st4(ro, soff[j], m0 ? acc[0] : eo_cur[j].x, m1 ? acc[1] : eo_cur[j].y, m2 ? acc[2] : eo_cur[j].z,
+                    m3 ? acc[3] : eo_cur[j].w);
         }
         po += p.plane;
     }
