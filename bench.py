@@ -80,9 +80,9 @@ def cpu_baseline(kind, radius, n, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--variant", default="fdtd4", choices=sorted(VARIANTS))
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--variant", default="jacobi", choices=sorted(VARIANTS))
     ap.add_argument("--n", type=int, default=512, help="slab edge: every GPU owns n planes of n x n cells")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--all-variants", action="store_true", help="also time every other variant (N=1 only)")
@@ -124,13 +124,27 @@ def main():
             be.st.initMt("p0", "p1")
         prog = make_program(kind, radius=radius)
         run = SlabRunner(be, radius, prog, rank, world)
-        run.run("p0", "p1", warmup)
+        cs = torch.cuda.current_stream().cuda_stream
+
+        def loop(k):
+            if world == 1:
+                # one rank: the whole time loop runs inside the library (fdtdx_sweep, the drivers'
+                # loop of fdtd1.cu:68-80), which fuses two steps per launch where it can
+                be.st.sweep("p0", "p1", prog, k, cs)
+            else:
+                run.run("p0", "p1", k)
+
+        def launches():
+            return int(be.st.lastLaunchInfo().rsplit("launches=", 1)[1])
+
+        loop(warmup)
         barrier()
+        l0 = launches()
         stream = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         e0.record(stream)
-        run.run("p0", "p1", steps)
+        loop(steps)
         e1.record(stream)
         barrier()
         dt = time.perf_counter() - t0
@@ -142,16 +156,23 @@ def main():
         cells_rank = float(run.z_hi - run.z_lo) * float(n - 2 * radius) ** 2   # this rank, one step
         cells_all = (float(n * world - 2 * radius)) * float(n - 2 * radius) ** 2
         info = be.st.lastLaunchInfo()
+        nl_ = launches() - l0 if world == 1 else None
         be.st.close()
         del be
         torch.cuda.empty_cache()
-        return dict(dt=dt, ev_ms=ev_ms, cells_rank=cells_rank, cells_all=cells_all, info=info, kind=kind, radius=radius)
+        nl = nl_
+        return dict(dt=dt, ev_ms=ev_ms, cells_rank=cells_rank, cells_all=cells_all, info=info, kind=kind, radius=radius,
+                    launches=nl)
 
     r = time_variant(a.variant, a.steps, a.warmup)
     value = r["cells_all"] * a.steps / r["dt"] * 1e-9
-    # dominant kernel = the sweep; at N=1 a step is exactly one launch of it
-    launch_s = r["ev_ms"] * 1e-3 / a.steps
-    achieved = BYTES_PER_UPDATE * r["cells_rank"] / launch_s * 1e-9
+    # dominant kernel = the sweep.  One launch advances `steps_per_launch` time steps (2 where the
+    # fused kernel applies, else 1): algorithmic bytes per launch = 8 B x cells x steps per launch,
+    # launch duration = HIP-event time over the timed region / launches issued in it.
+    nlaunch = r["launches"] or a.steps
+    steps_per_launch = a.steps / nlaunch
+    launch_s = r["ev_ms"] * 1e-3 / nlaunch
+    achieved = BYTES_PER_UPDATE * r["cells_rank"] * steps_per_launch / launch_s * 1e-9
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
@@ -171,7 +192,8 @@ def main():
                    "kernel": r["info"]},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": BYTES_PER_UPDATE * r["cells_rank"],
+                     "algorithmic_bytes_per_launch": BYTES_PER_UPDATE * r["cells_rank"] * steps_per_launch,
+                     "launches": nlaunch, "steps_per_launch": round(steps_per_launch, 3),
                      "launch_us": round(launch_s * 1e6, 2)},
     }
     if a.all_variants and world == 1:

@@ -7,6 +7,7 @@
 // caller moves them with RCCL send/recv (fdtd_amd/slab.py) while the interior sweep runs.
 #include "../../include/fdtdx.h"
 #include "sweep_common.h"
+#include "tb_kernel.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -34,6 +35,14 @@ static std::vector<SpcVariantInfo> &sreg()
 int num_variants() { return (int)vreg().size(); }
 const VariantInfo *variant(int i) { return &vreg()[i]; }
 void register_variant(const VariantInfo &v) { vreg().push_back(v); }
+static std::vector<TbVariantInfo> &treg()
+{
+    static std::vector<TbVariantInfo> v;
+    return v;
+}
+int num_tb_variants() { return (int)treg().size(); }
+const TbVariantInfo *tb_variant(int i) { return &treg()[i]; }
+void register_tb_variant(const TbVariantInfo &v) { treg().push_back(v); }
 int num_spc_variants() { return (int)sreg().size(); }
 const SpcVariantInfo *spc_variant(int i) { return &sreg()[i]; }
 void register_spc_variant(const SpcVariantInfo &v) { sreg().push_back(v); }
@@ -72,7 +81,13 @@ struct fdtdx_ctx {
     std::map<std::string, Cube> pool;  // memoryPool of stencil.h:361
     int64_t opt_zchunks = 0;           // 0 = auto
     int64_t opt_variant = -1;          // -1 = auto
+    int64_t opt_temporal = 1;          // fuse two steps per launch where a fused kernel exists
+    int64_t opt_tb_variant = -1;       // shape of the fused kernel, -1 = auto
+    int64_t opt_tb_zchunks = 0;
+    float *tb_scratch = nullptr;       // third cube of the fused time loop (owned)
+    uint64_t launches = 0;             // sweep launches issued so far (bench bookkeeping)
     char last_launch[256] = "";
+    char last_fused[256] = "";         // last fused (two-step) launch, "" if none since creation
 };
 
 extern "C" const char *fdtdx_last_error(void) { return g_err; }
@@ -143,6 +158,7 @@ extern "C" int fdtdx_destroy(fdtdx_ctx *ctx)
     int rc = FDTDX_OK;
     for (auto &kv : ctx->pool)
         if (kv.second.owned && kv.second.ptr && hipFree(kv.second.ptr) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(%s) failed", kv.first.c_str());
+    if (ctx->tb_scratch && hipFree(ctx->tb_scratch) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(scratch) failed");
     delete ctx;
     return rc;
 }
@@ -450,6 +466,7 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
     p.gx = gx, p.gy = gy, p.gz = gz;
     launch(p, dim3((unsigned)gx * gy * gz), (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
+    ctx->launches++;
     snprintf(ctx->last_launch, sizeof(ctx->last_launch), "kind=%u r=%d order=%u tile=%dx%d(quads x rows) threads=%d ry=%d pf=%d lds=%d grid=%dx%dx%d zchunk=%d",
              prog->kind, r, prog->order, tq, ly * ry, threads, ry, pf, lds, gx, gy, gz, p.zchunk);
     return FDTDX_OK;
@@ -486,15 +503,109 @@ extern "C" int fdtdx_propagate(fdtdx_ctx *ctx, const char *out, const char *in, 
     return fdtdx_propagate_planes(ctx, out, in, prog, lo, hi, stream);
 }
 
+// Two fused steps out = f(f(in)) with level-1 shell cells taken from `mid` (tb_kernel.h).
+static const TbVariantInfo *pick_tb(const fdtdx_ctx *ctx, const fdtdx_program *prog)
+{
+    if (!ctx->opt_temporal || ctx->cfg.nprocs != 1 || prog->order != FDTDX_ORDER_CHAIN) return nullptr;
+    int ord;
+    if (prog->kind == FDTDX_STAR && prog->radius == 1)
+        ord = ORD_STAR_CHAIN;
+    else if (prog->kind == FDTDX_JACOBI7)
+        ord = ORD_JACOBI_CHAIN;
+    else
+        return nullptr;
+    const int nq = (int)((ctx->cfg.X + 3) / 4);
+    const TbVariantInfo *best = nullptr;
+    int idx = 0;
+    for (int i = 0; i < num_tb_variants(); i++) {
+        const TbVariantInfo *v = tb_variant(i);
+        if (v->order != ord || nq > 64 * v->rx) continue;
+        if (ctx->opt_tb_variant >= 0 ? idx == ctx->opt_tb_variant : !best) best = v;
+        idx++;
+    }
+    return best;
+}
+
+static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const float *in, const float *mid, const fdtdx_program *prog, void *stream)
+{
+    const fdtdx_geometry &g = ctx->g;
+    TbParams p;
+    p.in = in, p.mid = mid, p.out = out;
+    p.plane = (long long)g.plane;
+    p.px = (int)g.pitch_x, p.pxq = (int)(g.pitch_x / 4);
+    p.nx = (int)ctx->cfg.X, p.ny = (int)ctx->cfg.Y, p.nz = (int)g.local_planes;
+    p.z_lo = 1, p.z_hi = p.nz - 1;
+    memcpy(p.c, prog->coef, 7 * sizeof(float));
+    const int owned = v->nw * v->ry - 4;
+    p.gy = (p.ny - 2 + owned - 1) / owned;
+    const long long nz = p.z_hi - p.z_lo;
+    long long chunks = ctx->opt_tb_zchunks;
+    if (chunks <= 0) {
+        // the fused kernel runs one workgroup per CU (registers): the largest chunk count that
+        // keeps gy*gz within the 256 CUs, so the whole grid is resident in one round
+        chunks = std::max<long long>(1, 256 / p.gy);
+        chunks = std::min(chunks, std::max<long long>(1, nz / 16));
+    }
+    chunks = std::max<long long>(1, std::min(chunks, nz));
+    p.zchunk = (int)((nz + chunks - 1) / chunks);
+    p.gz = (int)((nz + p.zchunk - 1) / p.zchunk);
+    v->launch(p, dim3((unsigned)(p.gy * p.gz)), (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    ctx->launches++;
+    snprintf(ctx->last_fused, sizeof(ctx->last_fused), "fused2 kind=%u r=1 waves=%d rows/wave=%d quads/lane/row=%d tile_rows=%d(stored %d) threads=%d lds=%d grid=%dx%d zchunk=%d",
+             prog->kind, v->nw, v->ry, v->rx, v->nw * v->ry, owned, v->threads, v->lds_bytes, p.gy, p.gz, p.zchunk);
+    return FDTDX_OK;
+}
+
 extern "C" int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const fdtdx_program *prog, uint32_t steps, void *stream)
 {
     if (!ctx) return fail(FDTDX_ERR_INVALID, "null context");
     if (ctx->cfg.nprocs != 1) return fail(FDTDX_ERR_UNSUPPORTED, "fdtdx_sweep runs whole time loops on one rank only; use propagate + halo exchange per step");
-    const char *out = a, *in = b;
-    for (uint32_t t = 0; t < steps; t++) {
-        int rc = fdtdx_propagate(ctx, out, in, prog, stream);
+    int r;
+    int rc = check_program(ctx, prog, &r);
+    if (rc) return rc;
+    float *pa, *pb;
+    rc = find_cube(ctx, a, &pa);
+    if (rc) return rc;
+    rc = find_cube(ctx, b, &pb);
+    if (rc) return rc;
+    if (pa == pb) return fail(FDTDX_ERR_INVALID, "sweep needs two different cubes");
+    const fdtdx_geometry &g = ctx->g;
+    const uint64_t lo = r, hi = g.local_planes - r;
+    const TbVariantInfo *tb = steps >= 4 ? pick_tb(ctx, prog) : nullptr;
+    uint32_t done = 0;
+    if (tb) {
+        // Level t lives in b for even t and in a for odd t (step 0 writes a = f(b)).  Fused pairs
+        // hop between b and a third cube c that carries b's shell; a only lends its shell to the
+        // skipped odd levels.  The last one to three steps are single steps so that a and b end
+        // holding exactly the two newest levels, as after the reference's loop.
+        uint32_t pairs = (steps % 2 == 0) ? steps / 2 - 1 : ((steps - 1) / 2) & ~1u;
+        if (pairs > 0) {
+            const size_t bytes = g.cube_elems * sizeof(float);
+            if (!ctx->tb_scratch) HIP_TRY(hipMalloc((void **)&ctx->tb_scratch, bytes));
+            HIP_TRY(hipMemcpyAsync(ctx->tb_scratch, pb, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            float *cur = pb, *oth = ctx->tb_scratch;
+            for (uint32_t k = 0; k < pairs; k++) {
+                rc = launch_tb(ctx, tb, oth, cur, pa, prog, stream);
+                if (rc) return rc;
+                std::swap(cur, oth);
+            }
+            done = 2 * pairs;
+            if (cur != pb) {
+                // even step count, odd number of pairs: the newest even level sits in the scratch
+                // cube; the next single step reads it from there (b is rewritten afterwards)
+                rc = launch_sweep(ctx, pa, cur, prog, lo, hi, stream);
+                if (rc) return rc;
+                done++;
+            }
+        }
+    }
+    // remaining single steps: level `done` is in b if done is even, in a if odd
+    for (uint32_t t = done; t < steps; t++) {
+        float *out = (t % 2 == 0) ? pa : pb;
+        const float *in = (t % 2 == 0) ? pb : pa;
+        rc = launch_sweep(ctx, out, in, prog, lo, hi, stream);
         if (rc) return rc;
-        std::swap(out, in);
     }
     return FDTDX_OK;
 }
@@ -531,6 +642,12 @@ extern "C" int fdtdx_set_option(fdtdx_ctx *ctx, const char *key, int64_t value)
         ctx->opt_zchunks = value;
     else if (!strcmp(key, "variant"))
         ctx->opt_variant = value;
+    else if (!strcmp(key, "temporal"))
+        ctx->opt_temporal = value;
+    else if (!strcmp(key, "tb_variant"))
+        ctx->opt_tb_variant = value;
+    else if (!strcmp(key, "tb_zchunks"))
+        ctx->opt_tb_zchunks = value;
     else
         return fail(FDTDX_ERR_INVALID, "unknown option '%s'", key);
     return FDTDX_OK;
@@ -539,6 +656,6 @@ extern "C" int fdtdx_set_option(fdtdx_ctx *ctx, const char *key, int64_t value)
 extern "C" int fdtdx_last_launch_info(const fdtdx_ctx *ctx, char *buf, size_t len)
 {
     if (!ctx || !buf || !len) return fail(FDTDX_ERR_INVALID, "null argument");
-    snprintf(buf, len, "%s", ctx->last_launch);
+    snprintf(buf, len, "%s%s%s launches=%llu", ctx->last_launch, ctx->last_fused[0] ? " | " : "", ctx->last_fused, (unsigned long long)ctx->launches);
     return FDTDX_OK;
 }

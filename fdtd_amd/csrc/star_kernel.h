@@ -43,19 +43,6 @@ __device__ __forceinline__ float pair_or_chain(float acc, float cp, float vp, fl
     }
 }
 
-template <int I>
-struct PhaseTag {
-    static constexpr int value = I;
-};
-template <int PH, int N, class F>
-__device__ __forceinline__ void unroll_phases(F &&f)
-{
-    if constexpr (PH < N) {
-        f(PhaseTag<PH>{});
-        unroll_phases<PH + 1, N>(f);
-    }
-}
-
 constexpr int star_nhk(int M, int TQ, int LY, int RY)
 {
     return (2 * M * TQ + LY * RY * 2 * ((M + 3) / 4) + TQ * LY - 1) / (TQ * LY);

@@ -88,6 +88,21 @@ __device__ __forceinline__ void logical_tile(const SweepParams &p, int &bx, int 
     bz = t / p.gy;
 }
 
+// Compile-time loop: f(PhaseTag<PH>{}) for PH in [PH, N), used to unroll z loops whose register
+// queues rotate by renaming.
+template <int I>
+struct PhaseTag {
+    static constexpr int value = I;
+};
+template <int PH, int N, class F>
+__device__ __forceinline__ void unroll_phases(F &&f)
+{
+    if constexpr (PH < N) {
+        f(PhaseTag<PH>{});
+        unroll_phases<PH + 1, N>(f);
+    }
+}
+
 // Registry, filled by the per-radius translation units.
 int num_variants();
 const VariantInfo *variant(int i);

@@ -131,6 +131,6 @@ class Stencil:
         _lib.check(self._L.fdtdx_set_option(self._h, key.encode(), int(value)))
 
     def lastLaunchInfo(self):
-        buf = ctypes.create_string_buffer(256)
-        _lib.check(self._L.fdtdx_last_launch_info(self._h, buf, 256))
+        buf = ctypes.create_string_buffer(640)
+        _lib.check(self._L.fdtdx_last_launch_info(self._h, buf, 640))
         return buf.value.decode()

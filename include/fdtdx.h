@@ -157,9 +157,12 @@ int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const fdtdx_progra
 int fdtdx_halo_region(fdtdx_ctx *ctx, const char *name, int side, int what, float **ptr, size_t *count);
 
 /* Kernel-selection knobs, for tuning and tests: "zchunks" (z-chunks per sweep launch, 0 = auto),
- * "variant" (tile-shape index, -1 = auto). */
+ * "variant" (tile-shape index, -1 = auto), "temporal" (1 = fdtdx_sweep fuses two time steps per
+ * launch where a fused kernel exists, 0 = one launch per step), "tb_variant" / "tb_zchunks" (shape
+ * and z-chunks of the fused kernel). */
 int fdtdx_set_option(fdtdx_ctx *ctx, const char *key, int64_t value);
-/* Describes the kernel the last sweep launched (tile shape, grid, LDS), for logs and bench. */
+/* Describes the kernels the last sweeps launched (tile shape, grid, LDS; the last fused launch if
+ * any; launches issued so far), for logs and bench. */
 int fdtdx_last_launch_info(const fdtdx_ctx *ctx, char *buf, size_t len);
 
 #ifdef __cplusplus

@@ -1,0 +1,122 @@
+// fdtdx/stencil.hpp -- C++ face of the C ABI (fdtdx.h) with the reference's `Stencil<>` method names.
+//
+// Source-level stand-in for the host class of the reference (stencil.h:357-842) on the sweep path:
+// the same template header <DataType, ZSize, YSize, XSize, M, FDTD>, the same method names and
+// argument order, the same error behaviour (message to stderr, then abort -- stencil.h:16-22).
+// What changes at the call site: the device lambda passed to propagate() becomes an
+// `fdtdx_program` (a C ABI cannot carry a lambda), and rank/nprocs come from the constructor
+// instead of MPI::COMM_WORLD (the launcher owns the communicator here).
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <type_traits>
+#include <utility>
+
+#include "../fdtdx.h"
+
+#define FDTDX_ASSERT(expr)                                                                 \
+    do {                                                                                   \
+        int rc_ = (expr);                                                                  \
+        if (rc_ != FDTDX_OK) {                                                             \
+            std::fprintf(stderr, "ERROR AT [ %s ] : %s\n", #expr, fdtdx_last_error());     \
+            std::abort();                                                                  \
+        }                                                                                  \
+    } while (0)
+
+namespace fdtdx {
+
+// Programs of the shipped drivers.
+inline fdtdx_program star_program(unsigned radius, unsigned order = FDTDX_ORDER_CHAIN)
+{  // fdtdN.cu:61-64 .. fdtd8.cu:82-93
+    fdtdx_program p{};
+    p.kind = FDTDX_STAR, p.radius = radius, p.order = order;
+    const float c[7] = {0.01f, 0.02f, 0.03f, 0.04f, 0.05f, 0.06f, 0.07f};
+    for (int i = 0; i < 7; i++) p.coef[i] = c[i];
+    return p;
+}
+inline fdtdx_program spc13_program(unsigned order = FDTDX_ORDER_CHAIN)
+{  // fdtdspc.cu:64-73
+    fdtdx_program p{};
+    p.kind = FDTDX_SPC13, p.radius = 1, p.order = order;
+    const float c[13] = {0.01f, 0.02f, 0.03f, 0.04f, 0.05f, 0.06f, 0.07f, 0.02f, 0.03f, 0.04f, 0.05f, 0.06f, 0.07f};
+    for (int i = 0; i < 13; i++) p.coef[i] = c[i];
+    return p;
+}
+inline fdtdx_program jacobi7_program(unsigned order = FDTDX_ORDER_CHAIN)
+{  // jacobi.cu:15-21,31-38
+    fdtdx_program p{};
+    p.kind = FDTDX_JACOBI7, p.radius = 1, p.order = order;
+    const float c[7] = {0.01f, 0.02f, 0.03f, 0.04f, 0.05f, 0.06f, 0.07f};
+    for (int i = 0; i < 7; i++) p.coef[i] = c[i];
+    return p;
+}
+
+template <typename DataType, size_t ZSize, size_t YSize, size_t XSize, size_t M, bool FDTD = true>
+class Stencil {
+    static_assert(std::is_same<DataType, float>::value, "the sweep kernels are fp32 (every shipped driver uses float)");
+    fdtdx_ctx *ctx_ = nullptr;
+    fdtdx_geometry g_{};
+
+public:
+    // stencil.h:385-413; rank/nprocs: the z-slab this process owns (MPI rank/size in the reference)
+    explicit Stencil(unsigned rank = 0, unsigned nprocs = 1, int device = -1)
+    {
+        fdtdx_config cfg{};
+        cfg.Z = ZSize, cfg.Y = YSize, cfg.X = XSize, cfg.M = (unsigned)M;
+        cfg.rank = rank, cfg.nprocs = nprocs, cfg.device = device;
+        FDTDX_ASSERT(fdtdx_create(&cfg, &ctx_));
+        FDTDX_ASSERT(fdtdx_get_geometry(ctx_, &g_));
+    }
+    ~Stencil() { fdtdx_destroy(ctx_); }  // stencil.h:415-418 (no MPI::Finalize here)
+    Stencil(const Stencil &) = delete;
+    Stencil &operator=(const Stencil &) = delete;
+
+    size_t getRank() { return (size_t)fdtdx_rank(ctx_); }     // stencil.h:420-423
+    size_t getProcs() { return (size_t)fdtdx_nprocs(ctx_); }  // stencil.h:425-428
+    void sync() { FDTDX_ASSERT(fdtdx_sync(ctx_)); }           // stencil.h:430-433
+    const fdtdx_geometry &geometry() const { return g_; }
+    fdtdx_ctx *handle() { return ctx_; }
+
+    // stencil.h:553-582,468-477.  create_halo is accepted and ignored: ghost planes live in the cube.
+    DataType *mallocCube(const std::string &name, bool create_halo = false)
+    {
+        (void)create_halo;
+        FDTDX_ASSERT(fdtdx_malloc_cube(ctx_, name.c_str()));
+        return getCube(name);
+    }
+    void free(const std::string &name) { FDTDX_ASSERT(fdtdx_free(ctx_, name.c_str())); }
+    DataType *getCube(const std::string &name)
+    {
+        float *p = nullptr;
+        FDTDX_ASSERT(fdtdx_get_cube(ctx_, name.c_str(), &p));
+        return p;
+    }
+    // stencil.h:596-637 (the cross-rank gather of :623-636 is the launcher's job)
+    void transferCubeToGPU(const std::string &name, DataType *cpu) { FDTDX_ASSERT(fdtdx_transfer_cube_to_gpu(ctx_, name.c_str(), cpu)); }
+    void transferCubeToCPU(DataType *cpu, const std::string &name) { FDTDX_ASSERT(fdtdx_transfer_cube_to_cpu(ctx_, cpu, name.c_str())); }
+
+    // stencil.h:684-768.  `spill` only chose launch bounds in the reference; ignored.
+    void propagate(const std::string &output, const std::string &input, bool spill, const fdtdx_program &prog, void *stream = nullptr)
+    {
+        (void)spill;
+        FDTDX_ASSERT(fdtdx_propagate(ctx_, output.c_str(), input.c_str(), &prog, stream));
+    }
+    // the drivers' whole loop on one rank (fdtd1.cu:68-80): `steps` ping-pong steps, step 0 writes a = f(b)
+    void sweep(const std::string &a, const std::string &b, const fdtdx_program &prog, unsigned steps, void *stream = nullptr)
+    {
+        FDTDX_ASSERT(fdtdx_sweep(ctx_, a.c_str(), b.c_str(), &prog, steps, stream));
+    }
+    // commCubeHalo (stencil.h:639-647): where the planes to send/receive are; the launcher moves them
+    std::pair<DataType *, size_t> haloRegion(const std::string &name, int side, int what)
+    {
+        float *p = nullptr;
+        size_t n = 0;
+        FDTDX_ASSERT(fdtdx_halo_region(ctx_, name.c_str(), side, what, &p, &n));
+        return {p, n};
+    }
+    void initMt(const std::string &p0, const std::string &p1) { FDTDX_ASSERT(fdtdx_init_mt(ctx_, p0.c_str(), p1.c_str())); }  // fdtd1.cu:21-31
+    void initJacobi(const std::string &name) { FDTDX_ASSERT(fdtdx_init_jacobi(ctx_, name.c_str())); }                      // jacobi.cu:412-417
+};
+
+}  // namespace fdtdx

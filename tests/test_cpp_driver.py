@@ -1,0 +1,33 @@
+"""The C++ mirror header (include/fdtdx/stencil.hpp) compiles against the C ABI and the example
+driver links (CPU check); on the GPU box the built driver runs a short sweep."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "examples", "fdtd_driver")
+
+
+def build():
+    cmd = ["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "fdtd_driver.cpp"),
+           "-L" + os.path.join(ROOT, "fdtd_amd"), "-lfdtdx", "-Wl,-rpath," + os.path.join(ROOT, "fdtd_amd"),
+           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", EXE]
+    subprocess.check_call(cmd)
+
+
+def test_cpp_mirror_compiles_and_links():
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    build()
+    assert os.path.exists(EXE)
+
+
+@pytest.mark.gpu
+def test_cpp_driver_runs():
+    if not os.path.exists(EXE):
+        build()
+    out = subprocess.run([EXE, "4", "20"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "GPU time" in out.stdout and "checksum" in out.stdout

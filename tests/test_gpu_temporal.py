@@ -1,0 +1,68 @@
+"""The fused two-step kernel (fdtd_amd/csrc/tb_kernel.h) inside fdtdx_sweep: bit-exact against
+the CPU oracle's step-by-step loop, for every compiled shape, even and odd step counts, grids
+with several y tiles and z chunks, ragged x, and cubes whose two shells differ (the drivers'
+p0/p1 are independent random fields, fdtd1.cu:28-29)."""
+import numpy as np
+import pytest
+
+from fdtd_amd import Stencil, make_program
+
+pytestmark = pytest.mark.gpu
+
+
+def run(cpu, kind, shape, steps, tb_variant=-1, tb_zchunks=0, temporal=1):
+    Z, Y, X = shape
+    if kind == "jacobi7":
+        a = cpu.init_jacobi(Z, Y, X)
+        b = a.copy()
+    else:
+        a, b = cpu.init_mt(Z, Y, X)
+    ca, cb = a.copy(), b.copy()
+    cpu.run(kind, ca, cb, steps, M=1, order=cpu.ORDER_CHAIN)
+    with Stencil(Z, Y, X, 1) as st:
+        st.mallocCube("p0")
+        st.mallocCube("p1")
+        st.transferCubeToGPU("p0", a)
+        st.transferCubeToGPU("p1", b)
+        st.setOption("temporal", temporal)
+        st.setOption("tb_variant", tb_variant)
+        st.setOption("tb_zchunks", tb_zchunks)
+        st.sweep("p0", "p1", make_program(kind, radius=1), steps)
+        st.sync()
+        ga, gb = np.empty_like(a), np.empty_like(b)
+        st.transferCubeToCPU(ga, "p0")
+        st.transferCubeToCPU(gb, "p1")
+        info = st.lastLaunchInfo()
+    assert np.array_equal(ga.view(np.uint32), ca.view(np.uint32)), info
+    assert np.array_equal(gb.view(np.uint32), cb.view(np.uint32)), info
+    return info
+
+
+@pytest.mark.parametrize("steps", [4, 5, 6, 7, 8, 9, 11])
+@pytest.mark.parametrize("kind", ["star", "jacobi7"])
+def test_fused_step_counts(oracle_cpu, kind, steps):
+    info = run(oracle_cpu, kind, (13, 61, 509), steps, tb_zchunks=2)
+    assert "fused2" in info
+
+
+@pytest.mark.parametrize("variant", range(5))
+@pytest.mark.parametrize("kind", ["star", "jacobi7"])
+def test_every_fused_shape(oracle_cpu, kind, variant):
+    info = run(oracle_cpu, kind, (21, 75, 512), 6, tb_variant=variant, tb_zchunks=3)
+    assert "fused2" in info
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 3), (5, 7, 9), (9, 20, 21), (40, 19, 300), (7, 130, 64)])
+def test_fused_small_and_ragged(oracle_cpu, shape):
+    run(oracle_cpu, "star", shape, 6)
+
+
+def test_fused_falls_back_for_wide_rows(oracle_cpu):
+    """Rows wider than a wave can hold (X > 512) take the single-step path; results stay exact."""
+    info = run(oracle_cpu, "star", (9, 12, 700), 6)
+    assert "fused2" not in info
+
+
+def test_temporal_off_equals_on(oracle_cpu):
+    info = run(oracle_cpu, "star", (12, 40, 256), 8, temporal=0)
+    assert "fused2" not in info

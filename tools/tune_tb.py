@@ -1,0 +1,27 @@
+"""Times the fused two-step radius-1 kernel shapes at 512^3 (tuning aid)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from fdtd_amd import Stencil, make_program
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+steps = 100
+stream = torch.cuda.current_stream().cuda_stream
+import json
+plan = json.loads(sys.argv[2]) if len(sys.argv) > 2 else {str(v): [0, 2, 4, 8, 16] for v in range(5)}
+for kind in ("star",):
+    with Stencil(n, n, n, 1) as st:
+        st.mallocCube("p0"); st.mallocCube("p1")
+        if kind == "star":
+            st.initMt("p0", "p1")
+        else:
+            st.initJacobi("p0"); st.initJacobi("p1")
+        prog = make_program(kind, radius=1)
+        for v, zcs in sorted((int(k), z) for k, z in plan.items()):
+            for zc in zcs:
+                st.setOption("tb_variant", v); st.setOption("tb_zchunks", zc)
+                st.sweep("p0", "p1", prog, 6, stream); torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); st.sweep("p0", "p1", prog, steps, stream); e1.record(); torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / steps
+                print(f"{kind} v={v} zc={zc}: {ms*1e3:7.1f} us/step {(n-2)**3/ms*1e-6:7.1f} Gcell/s [{st.lastLaunchInfo().split('|')[-1].strip()}]", flush=True)
