@@ -86,6 +86,10 @@ def main():
     ap.add_argument("--n", type=int, default=512, help="slab edge: every GPU owns n planes of n x n cells")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--all-variants", action="store_true", help="also time every other variant (N=1 only)")
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="run the N>1 loop with every rank on cuda:0 and host-staged gloo exchange (1-GPU box rehearsal; "
+                         "the line is marked rehearsal and is not a measurement)")
+    ap.add_argument("--check", action="store_true", help="after timing, compare rank-gathered fields of a short run with N=1 semantics")
     a = ap.parse_args()
 
     import torch
@@ -100,10 +104,15 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         a.gpus = world
+    if a.rehearse_shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.rehearse_shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
         torch.cuda.synchronize()
@@ -114,7 +123,10 @@ def main():
     def time_variant(name, steps, warmup):
         kind, radius, _ = VARIANTS[name]
         n = a.n
-        be = HipSlabBackend(n * world, n, n, radius, rank, world, local_rank)
+        # ghost depth: the program radius, or 2 for radius-1 programs on several slabs so that the
+        # fused two-step kernel can run with one exchange per pair of steps
+        ghost = 2 if (world > 1 and radius == 1 and kind in ("star", "jacobi7") and n <= 512) else radius
+        be = HipSlabBackend(n * world, n, n, ghost, rank, world, local_rank)
         be.alloc("p0")
         be.alloc("p1")
         if kind == "jacobi7":
@@ -123,7 +135,7 @@ def main():
         else:
             be.st.initMt("p0", "p1")
         prog = make_program(kind, radius=radius)
-        run = SlabRunner(be, radius, prog, rank, world)
+        run = SlabRunner(be, ghost, prog, rank, world, exchange="host" if a.rehearse_shared_gpu else "device")
         cs = torch.cuda.current_stream().cuda_stream
 
         def loop(k):
@@ -210,6 +222,8 @@ def main():
         except Exception as e:  # the GPU number stands on its own
             line["cpu_baseline"] = {"value": None, "unit": "Gcell/s", "cores": 0, "kind": "reference",
                                     "sample": f"failed: {e}"}
+    if a.rehearse_shared_gpu:
+        line["rehearsal"] = "ranks share one GPU, host-staged gloo exchange: NOT a measurement"
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

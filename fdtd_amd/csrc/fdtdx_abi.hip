@@ -526,15 +526,18 @@ static const TbVariantInfo *pick_tb(const fdtdx_ctx *ctx, const fdtdx_program *p
     return best;
 }
 
-static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const float *in, const float *mid, const fdtdx_program *prog, void *stream)
+static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const float *in, const float *mid, const fdtdx_program *prog,
+                     uint64_t z_lo, uint64_t z_hi, void *stream)
 {
     const fdtdx_geometry &g = ctx->g;
+    if (z_lo >= z_hi) return FDTDX_OK;
     TbParams p;
     p.in = in, p.mid = mid, p.out = out;
     p.plane = (long long)g.plane;
     p.px = (int)g.pitch_x, p.pxq = (int)(g.pitch_x / 4);
     p.nx = (int)ctx->cfg.X, p.ny = (int)ctx->cfg.Y, p.nz = (int)g.local_planes;
-    p.z_lo = 1, p.z_hi = p.nz - 1;
+    p.zg0 = (int)g.first_global, p.nzg = (int)ctx->cfg.Z;
+    p.z_lo = (int)z_lo, p.z_hi = (int)z_hi;
     memcpy(p.c, prog->coef, 7 * sizeof(float));
     const int owned = v->nw * v->ry - 4;
     p.gy = (p.ny - 2 + owned - 1) / owned;
@@ -555,6 +558,32 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
     snprintf(ctx->last_fused, sizeof(ctx->last_fused), "fused2 kind=%u r=1 waves=%d rows/wave=%d quads/lane/row=%d tile_rows=%d(stored %d) threads=%d lds=%d grid=%dx%d zchunk=%d",
              prog->kind, v->nw, v->ry, v->rx, v->nw * v->ry, owned, v->threads, v->lds_bytes, p.gy, p.gz, p.zchunk);
     return FDTDX_OK;
+}
+
+extern "C" int fdtdx_propagate2_planes(fdtdx_ctx *ctx, const char *out, const char *in, const char *mid, const fdtdx_program *prog,
+                                       uint64_t z_lo, uint64_t z_hi, void *stream)
+{
+    if (!ctx) return fail(FDTDX_ERR_INVALID, "null context");
+    int r;
+    int rc = check_program(ctx, prog, &r);
+    if (rc) return rc;
+    float *po, *pi, *pm;
+    if ((rc = find_cube(ctx, out, &po)) || (rc = find_cube(ctx, in, &pi)) || (rc = find_cube(ctx, mid, &pm))) return rc;
+    if (po == pi || po == pm) return fail(FDTDX_ERR_INVALID, "fused sweep cannot write a cube it reads");
+    const int64_t saved = ctx->opt_temporal;
+    ctx->opt_temporal = 1;
+    const uint32_t np = ctx->cfg.nprocs;
+    ctx->cfg.nprocs = 1;  // pick_tb refuses slabs only because fdtdx_sweep has no exchange; here the caller exchanges
+    const TbVariantInfo *tb = pick_tb(ctx, prog);
+    ctx->cfg.nprocs = np;
+    ctx->opt_temporal = saved;
+    if (!tb) return fail(FDTDX_ERR_UNSUPPORTED, "no fused kernel for this program/grid (radius 1, device order, X <= 512 only)");
+    const fdtdx_geometry &g = ctx->g;
+    // two steps need two planes of support on each side: ghost planes, or the global shell
+    const uint64_t need_lo = g.ghost_lo ? 2 : 1, need_hi = g.ghost_hi ? 2 : 1;
+    if (z_lo < need_lo || z_hi > g.local_planes - need_hi || z_lo > z_hi)
+        return fail(FDTDX_ERR_INVALID, "fused plane range [%llu,%llu) needs 2 ghost planes towards a neighbour", (unsigned long long)z_lo, (unsigned long long)z_hi);
+    return launch_tb(ctx, tb, po, pi, pm, prog, z_lo, z_hi, stream);
 }
 
 extern "C" int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const fdtdx_program *prog, uint32_t steps, void *stream)
@@ -586,7 +615,7 @@ extern "C" int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const f
             HIP_TRY(hipMemcpyAsync(ctx->tb_scratch, pb, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
             float *cur = pb, *oth = ctx->tb_scratch;
             for (uint32_t k = 0; k < pairs; k++) {
-                rc = launch_tb(ctx, tb, oth, cur, pa, prog, stream);
+                rc = launch_tb(ctx, tb, oth, cur, pa, prog, 1, g.local_planes - 1, stream);
                 if (rc) return rc;
                 std::swap(cur, oth);
             }

@@ -36,8 +36,9 @@ struct TbParams {
     float *out;        // level 2: interior written, shell untouched
     long long plane;
     int px, pxq, nx, ny;
-    int nz;            // planes in the cube (single slab: local == global)
-    int z_lo, z_hi;    // output planes [z_lo, z_hi) within [1, nz-1)
+    int nz;            // planes in the local cube (ghost planes included)
+    int zg0, nzg;      // global z of local plane 0, planes of the global grid: global planes 0 and nzg-1 are shell
+    int z_lo, z_hi;    // local output planes [z_lo, z_hi); planes z_lo-2 .. z_hi+1 must exist or be global shell
     int zchunk;
     int gy, gz;        // y tiles, z chunks (1-D launch of gy*gz workgroups)
     float c[7];
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(NW * 64) void tb2_r1_kernel(const TbParams p)
                 }
         }
         // level-1 shell values for plane zs-1
-        const bool zsh = (zs - 1 <= 0) || (zs - 1 >= p.nz - 1);
+        const bool zsh = (p.zg0 + zs - 1 <= 0) || (p.zg0 + zs - 1 >= p.nzg - 1);
         const __amdgpu_buffer_rsrc_t r = mid_rsrc(zs - 1);
 #pragma unroll
         for (int j = 0; j < RY; j++)
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(NW * 64) void tb2_r1_kernel(const TbParams p)
         {
             float4 res[RY][RX];
             level_step<RY, RX, ORDER>(res, q0[OLD], q0[MID], q0[NEW], up0, dn0, c, lane);
-            const bool zsh = (pz - 1 <= 0) || (pz - 1 >= p.nz - 1);  // whole plane is shell
+            const bool zsh = (p.zg0 + pz - 1 <= 0) || (p.zg0 + pz - 1 >= p.nzg - 1);  // whole plane is shell
             // q1 rotates one step behind q0's naming: its OLD slot (plane pz-4) is dead, level-1
             // plane pz-1 goes there.  With q1 planes (pz-3, pz-2, pz-1) = (MID, NEW, OLD) slots.
 #pragma unroll
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(NW * 64) void tb2_r1_kernel(const TbParams p)
         // ---- loads for the next iteration: input plane pz+1 into the dead slot, shell source of plane pz
         {
             const __amdgpu_buffer_rsrc_t rn = in_rsrc((pz + 1 < pend) ? pz + 1 : -1);
-            const bool zshn = (pz <= 0) || (pz >= p.nz - 1);
+            const bool zshn = (p.zg0 + pz <= 0) || (p.zg0 + pz >= p.nzg - 1);
             const __amdgpu_buffer_rsrc_t rm = mid_rsrc((pz + 1 < pend) ? pz : -1);
 #pragma unroll
             for (int j = 0; j < RY; j++)

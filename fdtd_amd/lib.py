@@ -68,6 +68,7 @@ SYMBOLS = {
     "fdtdx_propagate": (ctypes.c_int, [_vp, _c, _c, _P(Program), _vp]),
     "fdtdx_propagate_planes": (ctypes.c_int, [_vp, _c, _c, _P(Program), ctypes.c_uint64, ctypes.c_uint64, _vp]),
     "fdtdx_propagate_ptr": (ctypes.c_int, [_vp, _vp, _vp, _P(Program), ctypes.c_uint64, ctypes.c_uint64, _vp]),
+    "fdtdx_propagate2_planes": (ctypes.c_int, [_vp, _c, _c, _c, _P(Program), ctypes.c_uint64, ctypes.c_uint64, _vp]),
     "fdtdx_sweep": (ctypes.c_int, [_vp, _c, _c, _P(Program), ctypes.c_uint32, _vp]),
     "fdtdx_halo_region": (ctypes.c_int, [_vp, _c, ctypes.c_int, ctypes.c_int, _P(_vp), _P(ctypes.c_size_t)]),
     "fdtdx_set_option": (ctypes.c_int, [_vp, _c, ctypes.c_int64]),
@@ -84,6 +85,14 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise FdtdxError(-1, f"{LIB_PATH} is missing: build it with `make -C fdtd_amd/csrc` "
                                  "(there is no CPU fallback)")
+        # PyTorch-ROCm wheels ship their own copy of the HIP runtime.  One process must not end up
+        # with two: if the system runtime libfdtdx.so links against is loaded first, a later
+        # `import torch` finds "No HIP GPUs".  Loading torch's libraries first makes both sides
+        # share the runtime torch ships.  torch is optional: without it nothing changes.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export it

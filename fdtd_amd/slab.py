@@ -53,6 +53,18 @@ class HipSlabBackend:
         if z_hi > z_lo:
             self.st.propagatePlanes(out, inp, program, z_lo, z_hi, torch.cuda.current_stream().cuda_stream)
 
+    def sweep2(self, out, inp, mid, program, z_lo, z_hi):
+        """Two fused steps out = f(f(inp)) on planes [z_lo, z_hi) (fdtdx_propagate2_planes)."""
+        if z_hi > z_lo:
+            self.st.propagate2Planes(out, inp, mid, program, z_lo, z_hi, torch.cuda.current_stream().cuda_stream)
+
+    def can_fuse(self, program):
+        return (program.order == _lib.ORDER_CHAIN and program.kind in (_lib.STAR, _lib.JACOBI7)
+                and (program.kind == _lib.JACOBI7 or program.radius == 1) and self.st.X <= 512)
+
+    def copy_cube(self, dst, src):
+        self.bufs[dst].copy_(self.bufs[src])
+
     def synchronize(self):
         torch.cuda.synchronize(self.device)
 
@@ -60,9 +72,13 @@ class HipSlabBackend:
 class SlabRunner:
     """The time loop of one rank.  `backend` provides alloc/planes/sweep/synchronize and `.g`."""
 
-    def __init__(self, backend, M, program, rank, nprocs, group=None):
+    def __init__(self, backend, M, program, rank, nprocs, group=None, exchange="device"):
+        """exchange: "device" hands the cube's own planes to the process group (RCCL on GPUs, gloo on
+        CPU tensors); "host" stages them through CPU tensors (rehearsals of the multi-rank loop on
+        a box whose ranks share one GPU, where RCCL cannot be used)."""
         self.b, self.M, self.prog = backend, M, program
         self.rank, self.nprocs, self.group = rank, nprocs, group
+        self.exchange = exchange
         g = backend.g
         self.local = int(g.local_planes)
         self.has_lo = int(g.ghost_lo) > 0
@@ -84,6 +100,32 @@ class SlabRunner:
             ops.append(dist.P2POp(dist.irecv, self.b.planes(name, self.local - M, M), self.rank + 1, self.group))
         return ops
 
+    def _start_exchange(self, name):
+        if self.nprocs <= 1:
+            return []
+        ops = self._exchange_ops(name)
+        if not ops:
+            return []
+        if self.exchange == "device":
+            return dist.batch_isend_irecv(ops)
+        # host staging: device -> CPU, P2P on CPU tensors, CPU -> device on wait
+        staged, cpu_ops = [], []
+        for op in ops:
+            t = op.tensor
+            h = t.cpu() if op.op is dist.isend else torch.empty(t.shape, dtype=t.dtype)
+            cpu_ops.append(dist.P2POp(op.op, h, op.peer, op.group))
+            if op.op is dist.irecv:
+                staged.append((t, h))
+        reqs = dist.batch_isend_irecv(cpu_ops)
+
+        class _Staged:
+            def wait(self_inner):
+                for r in reqs:
+                    r.wait()
+                for t, h in staged:
+                    t.copy_(h)
+        return [_Staged()]
+
     def step(self, out, inp):
         """out = f(inp) on the owned planes, then out's ghost planes = neighbours' new boundary planes."""
         M = self.M
@@ -95,22 +137,61 @@ class SlabRunner:
         if self.has_hi:
             ihi = max(hi - M, ilo)
             self.b.sweep(out, inp, self.prog, ihi, hi)
-        reqs = []
-        if self.nprocs > 1:
-            ops = self._exchange_ops(out)
-            if ops:
-                reqs = dist.batch_isend_irecv(ops)
+        reqs = self._start_exchange(out)
         self.b.sweep(out, inp, self.prog, ilo, ihi)
         for r in reqs:
             r.wait()
 
-    def run(self, a, b, steps):
-        """`steps` ping-pong steps: step 0 writes a = f(b) (fdtd1.cu:68-80)."""
-        out, inp = a, b
-        for _ in range(steps):
-            self.step(out, inp)
-            out, inp = inp, out
-        return inp, out  # (newest, previous)
+    def pair(self, out, inp, mid):
+        """Two fused steps out = f(f(inp)) and one exchange of the ghost-depth boundary planes of
+        `out`: half the launches, half the messages (same bytes) of two single steps."""
+        G = self.M
+        lo, hi = self.z_lo, self.z_hi
+        ilo, ihi = lo, hi
+        if self.has_lo:
+            ilo = min(lo + G, hi)
+            self.b.sweep2(out, inp, mid, self.prog, lo, ilo)
+        if self.has_hi:
+            ihi = max(hi - G, ilo)
+            self.b.sweep2(out, inp, mid, self.prog, ihi, hi)
+        reqs = self._start_exchange(out)
+        self.b.sweep2(out, inp, mid, self.prog, ilo, ihi)
+        for r in reqs:
+            r.wait()
+
+    def fusable(self):
+        """Two steps per launch need a fused kernel for the program and, towards a neighbour,
+        two ghost planes (context created with M >= 2 for a radius-1 program)."""
+        can = getattr(self.b, "can_fuse", None)
+        return bool(can and can(self.prog) and self.radius == 1 and (self.M >= 2 or not (self.has_lo or self.has_hi)))
+
+    def run(self, a, b, steps, fuse=True):
+        """`steps` ping-pong steps: step 0 writes a = f(b) (fdtd1.cu:68-80).  Where a fused kernel
+        exists the loop hops b -> c -> b two steps at a time (c: a third cube carrying b's shell,
+        a lends its shell to the skipped levels) and ends with 1-3 single steps, so that a and b
+        finish holding the two newest levels exactly as after the step-by-step loop."""
+        done = 0
+        if fuse and steps >= 4 and self.fusable():
+            pairs = steps // 2 - 1 if steps % 2 == 0 else ((steps - 1) // 2) & ~1
+            if pairs > 0:
+                c = "__fused_scratch"
+                if c not in self.b.bufs:
+                    self.b.alloc(c)
+                self.b.copy_cube(c, b)
+                cur, oth = b, c
+                for _ in range(pairs):
+                    self.pair(oth, cur, a)
+                    cur, oth = oth, cur
+                done = 2 * pairs
+                if cur != b:
+                    self.step(a, cur)
+                    done += 1
+        for t in range(done, steps):
+            if t % 2 == 0:
+                self.step(a, b)
+            else:
+                self.step(b, a)
+        return (a, b) if steps % 2 == 1 else (b, a)  # (newest, previous)
 
 
 def gather_cube(backend, name, Z, Y, X, rank, nprocs, group=None):

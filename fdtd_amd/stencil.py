@@ -112,6 +112,11 @@ class Stencil:
         _lib.check(self._L.fdtdx_propagate_planes(self._h, output.encode(), input.encode(), ctypes.byref(program),
                                                   z_lo, z_hi, ctypes.c_void_p(stream or 0)))
 
+    def propagate2Planes(self, output, input, mid, program, z_lo, z_hi, stream=None):
+        """Two fused steps output = f(f(input)) on local planes [z_lo, z_hi) (jacobi.cu:446-454)."""
+        _lib.check(self._L.fdtdx_propagate2_planes(self._h, output.encode(), input.encode(), mid.encode(),
+                                                   ctypes.byref(program), z_lo, z_hi, ctypes.c_void_p(stream or 0)))
+
     def sweep(self, a, b, program, steps, stream=None):
         """The drivers' whole time loop on one rank (fdtd1.cu:68-80)."""
         _lib.check(self._L.fdtdx_sweep(self._h, a.encode(), b.encode(), ctypes.byref(program), steps,

@@ -144,6 +144,15 @@ int fdtdx_propagate_planes(fdtdx_ctx *ctx, const char *out, const char *in, cons
 int fdtdx_propagate_ptr(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx_program *prog,
                         uint64_t z_lo, uint64_t z_hi, void *stream);
 
+/* Two fused time steps restricted to local planes [z_lo, z_hi): out = f(f(in)), the launch
+ * jacobi.cu:446-454 issues (temporal_blocking, jacobi.cu:115-400), generalised to cubes whose
+ * shells differ: cells of the skipped middle level that lie on the global shell are read from
+ * `mid` (the cube a single step would have written), and `out` must already hold the shell of
+ * `in`.  Radius-1 programs in device order only (FDTDX_ERR_UNSUPPORTED otherwise).  Towards a
+ * neighbouring slab the range needs two ghost planes (create the context with M >= 2). */
+int fdtdx_propagate2_planes(fdtdx_ctx *ctx, const char *out, const char *in, const char *mid,
+                            const fdtdx_program *prog, uint64_t z_lo, uint64_t z_hi, void *stream);
+
 /* The drivers' time loop on one rank (fdtd1.cu:68-80 with nprocs == 1): `steps` ping-pong
  * steps, step 0 writes a = f(b), then the roles swap.  On return cube `a`/`b` hold exactly what
  * the reference's two cubes hold after the same number of steps. */

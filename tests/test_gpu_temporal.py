@@ -66,3 +66,61 @@ def test_fused_falls_back_for_wide_rows(oracle_cpu):
 def test_temporal_off_equals_on(oracle_cpu):
     info = run(oracle_cpu, "star", (12, 40, 256), 8, temporal=0)
     assert "fused2" not in info
+
+
+@pytest.mark.parametrize("kind,steps", [("star", 8), ("jacobi7", 7)])
+def test_fused_on_two_slabs_equals_one(oracle_cpu, kind, steps):
+    """Fused pairs on a 2-way z split (ghost depth 2, one exchange per pair) on one GPU: the two
+    slabs run in this process and trade ghost planes by device copies.  Equal to the oracle's
+    undecomposed step-by-step result bit for bit."""
+    import torch
+    from fdtd_amd.slab import HipSlabBackend, SlabRunner
+    Z, Y, X, G = 48, 75, 512, 2
+    prog = make_program(kind, radius=1)
+    if kind == "jacobi7":
+        a = oracle_cpu.init_jacobi(Z, Y, X)
+        b = a.copy()
+    else:
+        a, b = oracle_cpu.init_mt(Z, Y, X)
+    bes = [HipSlabBackend(Z, Y, X, G, r, 2, 0) for r in range(2)]
+    for be in bes:
+        g = be.g
+        lo, n = int(g.first_global), int(g.local_planes)
+        for name, arr in (("p0", a), ("p1", b)):
+            be.alloc(name)
+            be.st.uploadLocal(name, arr[lo:lo + n])
+        be.alloc("c")
+        be.copy_cube("c", "p1")
+    runs = [SlabRunner(be, G, prog, r, 2) for r, be in enumerate(bes)]
+    assert all(r.fusable() for r in runs)
+
+    def exchange(name):
+        l0 = runs[0].local
+        bes[1].planes(name, 0, G).copy_(bes[0].planes(name, l0 - 2 * G, G))
+        bes[0].planes(name, l0 - G, G).copy_(bes[1].planes(name, G, G))
+
+    def single(out, inp):
+        for run in runs:
+            run.b.sweep(out, inp, prog, run.z_lo, run.z_hi)
+        exchange(out)
+
+    pairs = steps // 2 - 1 if steps % 2 == 0 else ((steps - 1) // 2) & ~1
+    cur, oth = "p1", "c"
+    for _ in range(pairs):
+        for run in runs:
+            run.b.sweep2(oth, cur, "p0", prog, run.z_lo, run.z_hi)
+        exchange(oth)
+        cur, oth = oth, cur
+    done = 2 * pairs
+    if cur != "p1":
+        single("p0", cur)
+        done += 1
+    for t in range(done, steps):
+        single("p0", "p1") if t % 2 == 0 else single("p1", "p0")
+    torch.cuda.synchronize()
+    got0 = np.concatenate([be.st.downloadOwned("p0") for be in bes], axis=0)
+    got1 = np.concatenate([be.st.downloadOwned("p1") for be in bes], axis=0)
+    oracle_cpu.run(kind, a, b, steps, M=1, order=oracle_cpu.ORDER_CHAIN)
+    for name, got, ref in (("p0", got0, a), ("p1", got1, b)):
+        bad = np.argwhere(got.view(np.uint32) != ref.view(np.uint32))
+        assert len(bad) == 0, f"{name}: {len(bad)} cells differ, first {bad[:4].tolist()} last {bad[-2:].tolist()}"

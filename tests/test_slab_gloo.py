@@ -24,6 +24,7 @@ class OracleSlabBackend:
 
     def __init__(self, cpu, Z, Y, X, M, rank, nprocs):
         self.cpu, self.Y, self.X, self.M = cpu, Y, X, M
+        self.Zg, self.fuse = Z, False
         self.g = lib.decompose(Z, Y, X, M, rank, nprocs)
         self.bufs = {}
 
@@ -51,11 +52,35 @@ class OracleSlabBackend:
         self.cpu.step(kind, dst, src, M=program.radius, order=self.cpu.ORDER_CHAIN, z_lo=z_lo, z_hi=z_hi)
         self.view3(out)[z_lo:z_hi, :, :self.X] = dst[z_lo:z_hi]
 
+    def sweep2(self, out, inp, mid, program, z_lo, z_hi):
+        """Two steps the slow way: level 1 on [z_lo-1, z_hi+1) into a copy of `mid` (which supplies
+        the shell of the skipped level), then level 2 on [z_lo, z_hi)."""
+        if z_hi <= z_lo:
+            return
+        kind = {lib.STAR: "star", lib.JACOBI7: "jacobi7"}[program.kind]
+        g = self.g
+        src = np.ascontiguousarray(self.view3(inp)[:, :, :self.X])
+        tmp = np.ascontiguousarray(self.view3(mid)[:, :, :self.X])
+        dst = np.ascontiguousarray(self.view3(out)[:, :, :self.X])
+        # level-1 planes that are interior planes of the GLOBAL grid
+        gz0, Zg = int(g.first_global), self.Zg
+        l1_lo = max(z_lo - 1, 1 - gz0)
+        l1_hi = min(z_hi + 1, Zg - 1 - gz0)
+        self.cpu.step(kind, tmp, src, M=1, order=self.cpu.ORDER_CHAIN, z_lo=l1_lo, z_hi=l1_hi)
+        self.cpu.step(kind, dst, tmp, M=1, order=self.cpu.ORDER_CHAIN, z_lo=z_lo, z_hi=z_hi)
+        self.view3(out)[z_lo:z_hi, :, :self.X] = dst[z_lo:z_hi]
+
+    def can_fuse(self, program):
+        return self.fuse
+
+    def copy_cube(self, dst, src):
+        self.bufs[dst].copy_(self.bufs[src])
+
     def synchronize(self):
         pass
 
 
-def _worker(rank, world, port, kind, M, shape, steps, q):
+def _worker(rank, world, port, kind, M, shape, steps, q, ghost=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -66,14 +91,15 @@ def _worker(rank, world, port, kind, M, shape, steps, q):
         b = a.copy()
     else:
         a, b = cpu.init_mt(Z, Y, X)
-    be = OracleSlabBackend(cpu, Z, Y, X, M, rank, world)
+    be = OracleSlabBackend(cpu, Z, Y, X, ghost or M, rank, world)
+    be.fuse = ghost is not None
     g = be.g
     lo, n = int(g.first_global), int(g.local_planes)
     be.alloc("p0")
     be.alloc("p1")
     be.upload_local("p0", a[lo:lo + n])
     be.upload_local("p1", b[lo:lo + n])
-    run = SlabRunner(be, M, make_program(kind, radius=M), rank, world)
+    run = SlabRunner(be, ghost or M, make_program(kind, radius=M), rank, world)
     run.run("p0", "p1", steps)
     o0, o1 = int(g.ghost_lo), int(g.ghost_lo) + int(g.owned_planes)
     q.put((rank, int(g.owned_begin), be.view3("p0")[o0:o1, :, :X].copy(), be.view3("p1")[o0:o1, :, :X].copy()))
@@ -118,6 +144,39 @@ def test_decomposition_invariance(oracle_cpu, world, kind, M, shape, steps):
     else:
         a, b = oracle_cpu.init_mt(Z, Y, X)
     oracle_cpu.run(kind, a, b, steps, M=M, order=oracle_cpu.ORDER_CHAIN)
+    assert np.array_equal(got0.view(np.uint32), a.view(np.uint32))
+    assert np.array_equal(got1.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("world,kind,shape,steps", [
+    (2, "star", (16, 9, 11), 6),
+    (2, "star", (16, 9, 11), 9),
+    (3, "jacobi7", (23, 8, 10), 8),
+    (2, "star", (14, 7, 9), 11),
+])
+def test_fused_pairs_on_slabs(oracle_cpu, world, kind, shape, steps):
+    """The two-steps-per-exchange loop (ghost depth 2) equals the undecomposed step-by-step update."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, 1, shape, steps, q, 2)) for r in range(world)]
+    for p in procs:
+        p.start()
+    parts = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    Z, Y, X = shape
+    got0, got1 = np.zeros(shape, np.float32), np.zeros(shape, np.float32)
+    for rank, begin, p0, p1 in parts:
+        got0[begin:begin + p0.shape[0]] = p0
+        got1[begin:begin + p1.shape[0]] = p1
+    if kind == "jacobi7":
+        a = oracle_cpu.init_jacobi(Z, Y, X)
+        b = a.copy()
+    else:
+        a, b = oracle_cpu.init_mt(Z, Y, X)
+    oracle_cpu.run(kind, a, b, steps, M=1, order=oracle_cpu.ORDER_CHAIN)
     assert np.array_equal(got0.view(np.uint32), a.view(np.uint32))
     assert np.array_equal(got1.view(np.uint32), b.view(np.uint32))
 
