@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- cell-update throughput of the sweep hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--variant fdtd4] [--n 512]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--variant fdtd4] [--size 512]
 
 A "step" is one time step of the drivers' loop (fdtd1.cu:68-80): one sweep of the whole slab
 plus, on N > 1 GPUs, the ghost-plane exchange with the z neighbours.  Weak scaling: every GPU
@@ -83,13 +83,12 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--variant", default="jacobi", choices=sorted(VARIANTS))
-    ap.add_argument("--n", type=int, default=512, help="slab edge: every GPU owns n planes of n x n cells")
+    ap.add_argument("--size", dest="n", type=int, default=512, help="slab edge: every GPU owns n planes of n x n cells")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--all-variants", action="store_true", help="also time every other variant (N=1 only)")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="run the N>1 loop with every rank on cuda:0 and host-staged gloo exchange (1-GPU box rehearsal; "
                          "the line is marked rehearsal and is not a measurement)")
-    ap.add_argument("--check", action="store_true", help="after timing, compare rank-gathered fields of a short run with N=1 semantics")
     a = ap.parse_args()
 
     import torch
@@ -151,7 +150,7 @@ def main():
 
         loop(warmup)
         barrier()
-        l0 = launches()
+        l0 = launches()  # sweep launches this rank has issued so far
         stream = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
@@ -168,7 +167,7 @@ def main():
         cells_rank = float(run.z_hi - run.z_lo) * float(n - 2 * radius) ** 2   # this rank, one step
         cells_all = (float(n * world - 2 * radius)) * float(n - 2 * radius) ** 2
         info = be.st.lastLaunchInfo()
-        nl_ = launches() - l0 if world == 1 else None
+        nl_ = launches() - l0
         be.st.close()
         del be
         torch.cuda.empty_cache()
@@ -181,6 +180,8 @@ def main():
     # dominant kernel = the sweep.  One launch advances `steps_per_launch` time steps (2 where the
     # fused kernel applies, else 1): algorithmic bytes per launch = 8 B x cells x steps per launch,
     # launch duration = HIP-event time over the timed region / launches issued in it.
+    # On several GPUs a step is split into boundary-plane and interior launches of the same kernel;
+    # the per-launch figures then describe the average of those.
     nlaunch = r["launches"] or a.steps
     steps_per_launch = a.steps / nlaunch
     launch_s = r["ev_ms"] * 1e-3 / nlaunch

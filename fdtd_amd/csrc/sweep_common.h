@@ -48,6 +48,9 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 // zeros and the store is dropped, which is how lanes are masked without branches.
 // the builtins traffic in GCC-style vectors; whole-vector bit casts only (a __builtin_bit_cast of
 // a single vector ELEMENT reads element 0 whichever index is written)
+#ifndef FDTDX_STORE_AUX
+#define FDTDX_STORE_AUX 0
+#endif
 typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
 typedef float f32x4 __attribute__((__vector_size__(16)));
 constexpr unsigned OOB = 0x80000000u;  // beyond any plane (planes are limited to 2^31-1 bytes)
@@ -68,7 +71,7 @@ __device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned voff,
     f[1] = b;
     f[2] = c;
     f[3] = d;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f), r, voff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f), r, voff, 0, FDTDX_STORE_AUX);
 }
 
 // Workgroups are dealt round-robin over the 8 XCDs (each with a private L2): hardware block b and

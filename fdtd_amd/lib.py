@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfdtdx.so")
+# FDTDX_LIB names another build of the same library (tuning experiments)
+LIB_PATH = os.environ.get("FDTDX_LIB") or os.path.join(_HERE, "libfdtdx.so")
 
 OK, ERR_INVALID, ERR_NOTFOUND, ERR_EXISTS, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM = range(7)
 STAR, SPC13, JACOBI7 = 0, 1, 2
