@@ -369,21 +369,29 @@ static int check_program(const fdtdx_ctx *ctx, const fdtdx_program *prog, int *r
 
 // Default tile shape per radius (quads x thread-rows x rows-per-thread), chosen from on-device
 // timings of every compiled shape on 512^3 grids (tools/tune.py).
-static void default_shape(int kind, int r, int *tq, int *ly, int *ry)
+// Tile shapes measured fastest at 512^3 (tools/tune.py).  Radius <= 4 runs full-row tiles (no x
+// halo at X <= 512) when the grid is wide enough to fill them; larger radii need the registers
+// for the z queue and use 32-quad tiles.
+static void default_shape(int kind, int r, int nq, int *tq, int *ly, int *ry)
 {
     if (kind == FDTDX_SPC13) {
         *tq = 64, *ly = 4, *ry = 2;
         return;
     }
+    if (r <= 4) {
+        if (nq > 64)
+            *tq = 128, *ly = 8, *ry = 1;
+        else if (nq > 32)
+            *tq = 64, *ly = 16, *ry = 1;
+        else
+            *tq = 32, *ly = 32, *ry = 1;
+        return;
+    }
     switch (r) {
-    case 1: *tq = 128, *ly = 8, *ry = 1; break;
-    case 2: *tq = 128, *ly = 8, *ry = 1; break;
-    case 3: *tq = 64, *ly = 16, *ry = 1; break;
-    case 4: *tq = 32, *ly = 16, *ry = 2; break;
     case 5: *tq = 32, *ly = 16, *ry = 2; break;
     case 6: *tq = 32, *ly = 16, *ry = 2; break;
     case 7: *tq = 32, *ly = 16, *ry = 1; break;
-    default: *tq = 32, *ly = 16, *ry = 2; break;
+    default: *tq = 32, *ly = 32, *ry = 1; break;
     }
 }
 
@@ -415,7 +423,7 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
     int tq, ly, ry, threads, lds, pf = 1;
     void (*launch)(const SweepParams &, dim3, hipStream_t) = nullptr;
     int dtq, dly, dry;
-    default_shape(prog->kind, r, &dtq, &dly, &dry);
+    default_shape(prog->kind, r, (int)((ctx->cfg.X + 3) / 4), &dtq, &dly, &dry);
     if (prog->kind == FDTDX_SPC13) {
         const SpcVariantInfo *best = nullptr;
         int idx = 0;
@@ -451,11 +459,11 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
     if (chunks <= 0) {
         // one workgroup per CU (256 CUs) measured fastest: every extra z chunk re-reads 2r planes
         // to fill its queue, so split z only as far as needed to cover the chip, and keep the
-        // fill below ~1/8 of a chunk
+        // fill below ~1/6 of a chunk
         const long long tiles = (long long)gx * gy;
-        chunks = std::max<long long>(1, (256 + tiles - 1) / tiles);
+        chunks = std::max<long long>(1, 256 / tiles);  // never more workgroups than CUs: a second round would run nearly empty
         if (threads <= 256) chunks *= 2;  // small workgroups: two per CU
-        const long long min_len = std::max<long long>(16LL * r, 16);
+        const long long min_len = std::max<long long>(12LL * r, 16);
         chunks = std::min(chunks, std::max<long long>(1, nz / min_len));
     }
     chunks = std::max<long long>(1, std::min(chunks, nz));

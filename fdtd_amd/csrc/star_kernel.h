@@ -24,9 +24,12 @@
 //   * Quads that straddle the shell in x are stored whole: the shell components carry the
 //     value the output cube already holds there (read once per plane by those lanes only), so
 //     a row needs exactly one store instruction.
-//   * For M <= 4 the z loop is unrolled once per queue slot with rotating slot names, so the
-//     queue advances by renaming instead of register moves, and new planes are loaded straight
-//     into their final slot PF planes ahead of their first use (more bytes in flight per CU).
+//   * The z loop is unrolled once per queue slot with rotating slot names, so the queue advances
+//     by renaming instead of register moves, and new planes are loaded straight into their final
+//     slot PF planes ahead of their first use (more bytes in flight per CU).
+//   * The update runs on cell pairs (v_pk_mul/add/fma_f32), stores are non-temporal: the output
+//     is not read again by this sweep, and keeping it out of the way leaves the cache to the
+//     halo rows neighbouring tiles share.
 #pragma once
 #include "sweep_common.h"
 
@@ -40,6 +43,18 @@ __device__ __forceinline__ float pair_or_chain(float acc, float cp, float vp, fl
     } else {
         acc = __builtin_fmaf(cp, vp, acc);
         return __builtin_fmaf(cm, vm, acc);
+    }
+}
+
+// the same update on two neighbouring cells at once
+template <int ORDER>
+__device__ __forceinline__ f32x2 pair_or_chain2(f32x2 acc, float cp, f32x2 vp, float cm, f32x2 vm)
+{
+    if constexpr (ORDER == ORD_STAR_GOLDEN) {
+        return acc + (cp * vp + cm * vm);
+    } else {
+        acc = __builtin_elementwise_fma(f32x2{cp, cp}, vp, acc);
+        return __builtin_elementwise_fma(f32x2{cm, cm}, vm, acc);
     }
 }
 
@@ -119,21 +134,22 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
         constexpr int XB = 4 * HQ;  // index of the own quad's first cell in xs
         float acc[4];
         if constexpr (ORDER == ORD_STAR_CHAIN || ORDER == ORD_STAR_GOLDEN) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) acc[i] = c0 * xs[XB + i];
+            // two cells per instruction (v_pk_mul/add/fma_f32): cells 0,1 and 2,3 of the quad
+#define XP(i) f32x2{xs[(i)], xs[(i) + 1]}
+            f32x2 a01 = c0 * XP(XB), a23 = c0 * XP(XB + 2);
 #pragma unroll
             for (int r = 1; r <= M; r++) {
                 const float4 yp = row[r * LPQ], ym = row[-r * LPQ];
                 const float4 zp = q[j][QS(M + r)], zm = q[j][QS(M - r)];
-                const float ypv[4] = {yp.x, yp.y, yp.z, yp.w}, ymv[4] = {ym.x, ym.y, ym.z, ym.w};
-                const float zpv[4] = {zp.x, zp.y, zp.z, zp.w}, zmv[4] = {zm.x, zm.y, zm.z, zm.w};
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    acc[i] = pair_or_chain<ORDER>(acc[i], cxp, xs[XB + i + r], cxm, xs[XB + i - r]);
-                    acc[i] = pair_or_chain<ORDER>(acc[i], cyp, ypv[i], cym, ymv[i]);
-                    acc[i] = pair_or_chain<ORDER>(acc[i], czp, zpv[i], czm, zmv[i]);
-                }
+                a01 = pair_or_chain2<ORDER>(a01, cxp, XP(XB + r), cxm, XP(XB - r));
+                a01 = pair_or_chain2<ORDER>(a01, cyp, f32x2{yp.x, yp.y}, cym, f32x2{ym.x, ym.y});
+                a01 = pair_or_chain2<ORDER>(a01, czp, f32x2{zp.x, zp.y}, czm, f32x2{zm.x, zm.y});
+                a23 = pair_or_chain2<ORDER>(a23, cxp, XP(XB + 2 + r), cxm, XP(XB + 2 - r));
+                a23 = pair_or_chain2<ORDER>(a23, cyp, f32x2{yp.z, yp.w}, cym, f32x2{ym.z, ym.w});
+                a23 = pair_or_chain2<ORDER>(a23, czp, f32x2{zp.z, zp.w}, czm, f32x2{zm.z, zm.w});
             }
+#undef XP
+            acc[0] = a01.x, acc[1] = a01.y, acc[2] = a23.x, acc[3] = a23.y;
         } else {
             // jacobi.cu:31-38 order: ce*E + cw*W + cs*S + cn*N + ct*T + cb*B + cc*C
             // coefficient slots: c0=cc, cxp=ce, cxm=cw, cyp=cs, cym=cn, czp=ct, czm=cb
@@ -180,8 +196,6 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
     constexpr int NHK = star_nhk(M, TQ, LY, RY);
     static_assert(NHK == (NHQ + NT - 1) / NT, "halo count");
     constexpr int QT = 2 * M + 1 + PF;        // queue slots
-    constexpr bool ROTATE = (M <= 4);         // unroll the z loop QT times instead of shifting the queue
-    static_assert(ROTATE || PF == 1, "the shifting queue prefetches one plane ahead");
 
     __shared__ float4 lds[2][LROWS * LPQ];
 
@@ -246,16 +260,14 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
     float4 q[RY][QT];
     float4 eo[RY];
     float4 hv[NHK];
-    // rotating: q[k] = plane zs-M+k for k < QT-1, slot QT-1 is loaded by the first step;
-    // shifting: q[k+1] = plane zs-M+k, the loop shifts down by one before each step.
-    constexpr int Q0 = ROTATE ? 0 : 1;
+    // q[k] = plane zs-M+k for k < QT-1; slot QT-1 is loaded by the first step
     const int zlast = p.z_hi + M;  // one past the last plane the sweep may read
 #pragma unroll
     for (int j = 0; j < RY; j++) {
 #pragma unroll
         for (int k = 0; k < QT - 1; k++)
-            q[j][k + Q0] = buf_ld4(make_rsrc(pin + (long long)k * p.plane, (zs - M + k < zlast) ? plane_bytes : 0u), L.goff[j]);
-        q[j][ROTATE ? QT - 1 : 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+            q[j][k] = buf_ld4(make_rsrc(pin + (long long)k * p.plane, (zs - M + k < zlast) ? plane_bytes : 0u), L.goff[j]);
+        q[j][QT - 1] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float *pc = p.in + (long long)zs * p.plane;  // centre plane
     float *po = p.out + (long long)zs * p.plane;
@@ -270,29 +282,18 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
 #pragma unroll
     for (int i = 0; i < 7; i++) c[i] = p.c[i];
 
-    if constexpr (ROTATE) {
-        int z = zs;
-        int par = 0;
-        while (z < ze) {
-            unroll_phases<0, QT>([&](auto ph) {
-                if (z < ze) {
-                    plane_step<M, TQ, LY, RY, ORDER, PF, decltype(ph)::value>(q, eo, hv, L, lds[par], pn, pc, po, z < zn_end,
-                                                                            z + 1 < ze, plane_bytes, c);
-                    par ^= 1;
-                    z++;
-                }
-            });
-        }
-    } else {
-        for (int z = zs; z < ze; z++) {
-#pragma unroll
-            for (int j = 0; j < RY; j++) {
-#pragma unroll
-                for (int k = 0; k < QT - 1; k++) q[j][k] = q[j][k + 1];
+    // one copy of the plane body per queue slot: the queue advances by renaming, never by moves
+    int z = zs;
+    int par = 0;
+    while (z < ze) {
+        unroll_phases<0, QT>([&](auto ph) {
+            if (z < ze) {
+                plane_step<M, TQ, LY, RY, ORDER, PF, decltype(ph)::value>(q, eo, hv, L, lds[par], pn, pc, po, z < zn_end, z + 1 < ze,
+                                                                        plane_bytes, c);
+                par ^= 1;
+                z++;
             }
-            plane_step<M, TQ, LY, RY, ORDER, PF, 0>(q, eo, hv, L, lds[(z - zs) & 1], pn, pc, po, z < zn_end, z + 1 < ze,
-                                                    plane_bytes, c);
-        }
+        });
     }
 }
 

@@ -49,9 +49,10 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 // the builtins traffic in GCC-style vectors; whole-vector bit casts only (a __builtin_bit_cast of
 // a single vector ELEMENT reads element 0 whichever index is written)
 #ifndef FDTDX_STORE_AUX
-#define FDTDX_STORE_AUX 0
+#define FDTDX_STORE_AUX 2
 #endif
 typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((__vector_size__(16)));
 constexpr unsigned OOB = 0x80000000u;  // beyond any plane (planes are limited to 2^31-1 bytes)
 

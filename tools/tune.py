@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--zchunks", default="0")
     ap.add_argument("--out", default="")
+    ap.add_argument("--temporal", type=int, default=0, help="1: let sweep() fuse time steps")
     ap.add_argument("--variants", default="", help="comma list of variant indices (default: all)")
     a = ap.parse_args()
     n = a.n
@@ -35,6 +36,7 @@ def main():
                 st.mallocCube("p0")
                 st.mallocCube("p1")
                 st.initMt("p0", "p1")
+                st.setOption("temporal", a.temporal)
                 prog = make_program(kind, radius=M)
                 cells = float(n - 2 * M) ** 3
                 vlist = [int(x) for x in a.variants.split(',')] if a.variants else None
