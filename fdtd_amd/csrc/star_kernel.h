@@ -125,7 +125,17 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
         float xs[4 * (2 * HQ + 1)];
 #pragma unroll
         for (int s = -HQ; s <= HQ; s++) {
-            const float4 v = (s == 0) ? q[j][QS(M)] : row[s];
+            float4 v;
+            if (s != 0 && M % 4 != 0 && (s == -HQ || s == HQ)) {
+                // the outermost quads need 1..3 components only; read them whole all the same: the
+                // narrower reads the compiler would pick (4/8/12 bytes at a 16-byte lane stride) run
+                // into 2- to 4-way bank conflicts
+                f32x4 w = *reinterpret_cast<const f32x4 *>(&row[s]);
+                asm("" : "+v"(w));
+                v = make_float4(w[0], w[1], w[2], w[3]);
+            } else {
+                v = (s == 0) ? q[j][QS(M)] : row[s];
+            }
             xs[4 * (s + HQ) + 0] = v.x;
             xs[4 * (s + HQ) + 1] = v.y;
             xs[4 * (s + HQ) + 2] = v.z;
