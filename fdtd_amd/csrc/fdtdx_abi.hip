@@ -367,9 +367,7 @@ static int check_program(const fdtdx_ctx *ctx, const fdtdx_program *prog, int *r
     return FDTDX_OK;
 }
 
-// Default tile shape per radius (quads x thread-rows x rows-per-thread), chosen from on-device
-// timings of every compiled shape on 512^3 grids (tools/tune.py).
-// Tile shapes measured fastest at 512^3 (tools/tune.py).  Radius <= 4 runs full-row tiles (no x
+// Default tile shape per radius (quads x thread-rows x rows-per-thread).  Tile shapes measured fastest at 512^3 (tools/tune.py).  Radius <= 4 runs full-row tiles (no x
 // halo at X <= 512) when the grid is wide enough to fill them; larger radii need the registers
 // for the z queue and use 32-quad tiles.
 static void default_shape(int kind, int r, int nq, int *tq, int *ly, int *ry)
@@ -522,12 +520,11 @@ static const TbVariantInfo *pick_tb(const fdtdx_ctx *ctx, const fdtdx_program *p
         ord = ORD_JACOBI_CHAIN;
     else
         return nullptr;
-    const int nq = (int)((ctx->cfg.X + 3) / 4);
     const TbVariantInfo *best = nullptr;
     int idx = 0;
     for (int i = 0; i < num_tb_variants(); i++) {
         const TbVariantInfo *v = tb_variant(i);
-        if (v->order != ord || nq > 64 * v->rx) continue;
+        if (v->order != ord) continue;
         if (ctx->opt_tb_variant >= 0 ? idx == ctx->opt_tb_variant : !best) best = v;
         idx++;
     }
@@ -549,22 +546,36 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
     memcpy(p.c, prog->coef, 7 * sizeof(float));
     const int owned = v->nw * v->ry - 4;
     p.gy = (p.ny - 2 + owned - 1) / owned;
+    const int nq = (p.nx + 3) / 4, tq = 64 * v->rx;
+    if (nq <= tq)
+        p.gx = 1, p.qstep = tq, p.qbase = 0;
+    else
+        p.qstep = tq - 2, p.qbase = -1, p.gx = (nq + p.qstep - 1) / p.qstep;
     const long long nz = p.z_hi - p.z_lo;
     long long chunks = ctx->opt_tb_zchunks;
     if (chunks <= 0) {
-        // the fused kernel runs one workgroup per CU (registers): the largest chunk count that
-        // keeps gy*gz within the 256 CUs, so the whole grid is resident in one round
-        chunks = std::max<long long>(1, 256 / p.gy);
-        chunks = std::min(chunks, std::max<long long>(1, nz / 16));
+        // The fused kernel runs one workgroup per CU (registers, LDS), so N workgroups take
+        // ceil(N/256) rounds of the 256 CUs, and every chunk pays for filling its queues (2 planes
+        // re-read, plus start-up: about 6 planes' worth in all, from timings at 512^3 and 1024^3):
+        // take the chunk count with the best product of the two efficiencies.
+        const long long tiles = (long long)p.gx * p.gy;
+        double best = -1.0;
+        chunks = 1;
+        for (long long cnt = 1; cnt <= std::max<long long>(1, nz / 16) && cnt * tiles <= 4096; cnt++) {
+            const long long len = (nz + cnt - 1) / cnt, n = tiles * ((nz + len - 1) / len);
+            const double eff = (double)n / (double)((n + 255) / 256 * 256) * (double)len / (double)(len + 6);
+            if (eff > best + 1e-9) best = eff, chunks = cnt;
+        }
     }
     chunks = std::max<long long>(1, std::min(chunks, nz));
     p.zchunk = (int)((nz + chunks - 1) / chunks);
     p.gz = (int)((nz + p.zchunk - 1) / p.zchunk);
-    v->launch(p, dim3((unsigned)(p.gy * p.gz)), (hipStream_t)stream);
+    if ((long long)p.gx * p.gy * p.gz > 0x7fffffffLL) return fail(FDTDX_ERR_UNSUPPORTED, "grid too large");
+    v->launch(p, dim3((unsigned)(p.gx * p.gy * p.gz)), (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     ctx->launches++;
-    snprintf(ctx->last_fused, sizeof(ctx->last_fused), "fused2 kind=%u r=1 waves=%d rows/wave=%d quads/lane/row=%d tile_rows=%d(stored %d) threads=%d lds=%d grid=%dx%d zchunk=%d",
-             prog->kind, v->nw, v->ry, v->rx, v->nw * v->ry, owned, v->threads, v->lds_bytes, p.gy, p.gz, p.zchunk);
+    snprintf(ctx->last_fused, sizeof(ctx->last_fused), "fused2 kind=%u r=1 waves=%d rows/wave=%d quads/lane/row=%d tile_rows=%d(stored %d) threads=%d lds=%d grid=%dx%dx%d zchunk=%d",
+             prog->kind, v->nw, v->ry, v->rx, v->nw * v->ry, owned, v->threads, v->lds_bytes, p.gx, p.gy, p.gz, p.zchunk);
     return FDTDX_OK;
 }
 
@@ -585,7 +596,7 @@ extern "C" int fdtdx_propagate2_planes(fdtdx_ctx *ctx, const char *out, const ch
     const TbVariantInfo *tb = pick_tb(ctx, prog);
     ctx->cfg.nprocs = np;
     ctx->opt_temporal = saved;
-    if (!tb) return fail(FDTDX_ERR_UNSUPPORTED, "no fused kernel for this program/grid (radius 1, device order, X <= 512 only)");
+    if (!tb) return fail(FDTDX_ERR_UNSUPPORTED, "no fused kernel for this program (radius 1, device order only)");
     const fdtdx_geometry &g = ctx->g;
     // two steps need two planes of support on each side: ghost planes, or the global shell
     const uint64_t need_lo = g.ghost_lo ? 2 : 1, need_hi = g.ghost_hi ? 2 : 1;

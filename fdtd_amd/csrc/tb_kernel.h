@@ -6,7 +6,8 @@
 //
 // Organisation (different from the single-step kernels on purpose: everything that is reused
 // stays in registers, LDS only carries what crosses a wave):
-//   * one WAVE owns RY consecutive rows over the WHOLE x extent: lane l holds quads l, l+64, ...
+//   * one WAVE owns RY consecutive rows over 64*RX quads (the whole x extent up to X = 256*RX;
+//     wider rows are cut into x tiles overlapping by one quad): lane l holds quads l, l+64, ...
 //     (RX per row), so a wave-load is 1 KiB contiguous and every x neighbour lives in the same
 //     wave: it is fetched with a DPP wave rotate, no LDS.
 //   * y neighbours between the rows of one wave are registers of the same lane; only the first
@@ -40,7 +41,8 @@ struct TbParams {
     int zg0, nzg;      // global z of local plane 0, planes of the global grid: global planes 0 and nzg-1 are shell
     int z_lo, z_hi;    // local output planes [z_lo, z_hi); planes z_lo-2 .. z_hi+1 must exist or be global shell
     int zchunk;
-    int gy, gz;        // y tiles, z chunks (1-D launch of gy*gz workgroups)
+    int gx, gy, gz;    // x tiles, y tiles, z chunks (1-D launch of gx*gy*gz workgroups)
+    int qstep, qbase;  // x tile bx loads quads [qbase + bx*qstep, +64*RX); one tile: qbase 0, else -1 (see kernel)
     float c[7];
 };
 
@@ -120,13 +122,17 @@ __global__ __launch_bounds__(NW * 64) void tb2_r1_kernel(const TbParams p)
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int by, bz;
+    int bx, by, bz;
     {
         SweepParams g;  // only the grid fields are read by logical_tile
-        g.gx = 1, g.gy = p.gy, g.gz = p.gz;
-        int bx;
+        g.gx = p.gx, g.gy = p.gy, g.gz = p.gz;
         logical_tile(g, bx, by, bz);
     }
+    // Rows wider than one wave's 64*RX quads are cut into x tiles that overlap by one quad on each
+    // side: the outermost quad of a tile only feeds its neighbours' level-1 values (a level-2
+    // cell reaches two cells, i.e. never beyond the adjacent quad) and is stored by the next tile.
+    const int tq0 = p.qbase + bx * p.qstep;
+    const bool xtiled = p.gx > 1;
     const int zs = p.z_lo + bz * p.zchunk;
     const int ze = min(zs + p.zchunk, p.z_hi);
     if (zs >= ze) return;
@@ -146,18 +152,20 @@ __global__ __launch_bounds__(NW * 64) void tb2_r1_kernel(const TbParams p)
         const bool yown = (y >= yown0) && (y < yown1);
 #pragma unroll
         for (int i = 0; i < RX; i++) {
-            const int qx = lane + 64 * i;
+            const int lq = lane + 64 * i;
+            const int qx = tq0 + lq;
             const int x0 = 4 * qx;
+            const bool xown = !xtiled || (lq >= 1 && lq < 64 * RX - 1);
             unsigned m = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 if (yin && x0 + k >= 1 && x0 + k < p.nx - 1) m |= 1u << k;
-            const bool qdom = ydom && (qx < p.pxq);
+            const bool qdom = ydom && (qx >= 0) && (qx < p.pxq);
             const unsigned off = (unsigned)(y * p.px + x0) * 4u;
             imask[j][i] = m;
             goff[j][i] = qdom ? off : OOB;
             moff[j][i] = (qdom && x0 < p.nx && m != 0xFu) ? off : OOB;
-            soff[j][i] = (qdom && yown && m != 0u) ? off : OOB;
+            soff[j][i] = (qdom && yown && xown && m != 0u) ? off : OOB;
         }
     }
     float c[7];

@@ -60,7 +60,7 @@ class HipSlabBackend:
 
     def can_fuse(self, program):
         return (program.order == _lib.ORDER_CHAIN and program.kind in (_lib.STAR, _lib.JACOBI7)
-                and (program.kind == _lib.JACOBI7 or program.radius == 1) and self.st.X <= 512)
+                and (program.kind == _lib.JACOBI7 or program.radius == 1))
 
     def copy_cube(self, dst, src):
         self.bufs[dst].copy_(self.bufs[src])

@@ -150,3 +150,37 @@ def test_thousand_step_value_classes(oracle_cpu, M):
     assert np.array_equal(classes(ga), classes(a)) and np.array_equal(classes(gb), classes(b))
     fin = np.isfinite(a)
     assert np.array_equal(ga[fin].view(np.uint32), a[fin].view(np.uint32))
+
+
+@pytest.mark.parametrize("kind,M", [("star", 2), ("spc13", 1), ("jacobi7", 1)])
+def test_offsets_beyond_32_bits(oracle_cpu, kind, M):
+    """A cube of more than 2^31 elements (the reference's uint32_t indices stop at 2^32,
+    fdtd1.cu:13-14): a block of planes at the far end of the cube, whose element offsets need
+    more than 31 bits and whose byte offsets more than 33, must come out as the oracle computes
+    it for the same block taken alone.  Rows are 1000 cells wide: two tiles in x for every shape."""
+    Z, Y, X, K = 2100, 1024, 1000, 12
+    rng = np.random.default_rng(7)
+    hin = rng.random((K, Y, X), dtype=np.float32)
+    hout = rng.random((K, Y, X), dtype=np.float32)
+    exp = hout.copy()
+    oracle_cpu.step(kind, exp, hin, M=M, order=1)
+    dev = torch.device("cuda", 0)
+    with Stencil(Z, Y, X, M) as st:
+        g = st.geometry
+        n, px = int(g.cube_elems), int(g.pitch_x)
+        assert n > 2 ** 31 and n * 4 > 2 ** 33
+        a = torch.zeros(n, dtype=torch.float32, device=dev)
+        b = torch.zeros(n, dtype=torch.float32, device=dev)
+        st.attachCube("p0", a.data_ptr(), n * 4)
+        st.attachCube("p1", b.data_ptr(), n * 4)
+        z0 = Z - K
+        a.view(Z, Y, px)[z0:, :, :X].copy_(torch.from_numpy(hout))
+        b.view(Z, Y, px)[z0:, :, :X].copy_(torch.from_numpy(hin))
+        st.propagatePlanes("p0", "p1", make_program(kind, radius=M), z0 + M, Z - M, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = a.view(Z, Y, px)[z0:, :, :X].cpu().numpy()
+        below = a.view(Z, Y, px)[z0 - 1].abs().max().item()
+    del a, b
+    torch.cuda.empty_cache()
+    assert below == 0.0  # nothing written under the requested range
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))

@@ -57,10 +57,12 @@ def test_fused_small_and_ragged(oracle_cpu, shape):
     run(oracle_cpu, "star", shape, 6)
 
 
-def test_fused_falls_back_for_wide_rows(oracle_cpu):
-    """Rows wider than a wave can hold (X > 512) take the single-step path; results stay exact."""
-    info = run(oracle_cpu, "star", (9, 12, 700), 6)
-    assert "fused2" not in info
+@pytest.mark.parametrize("X", [513, 700, 1000, 1024, 1531])
+@pytest.mark.parametrize("kind", ["star", "jacobi7"])
+def test_fused_wide_rows_are_cut_into_x_tiles(oracle_cpu, kind, X):
+    """Rows wider than a wave holds (X > 512) are fused too, as x tiles overlapping by one quad."""
+    info = run(oracle_cpu, kind, (9, 30, X), 6)
+    assert "fused2" in info
 
 
 def test_temporal_off_equals_on(oracle_cpu):
