@@ -122,9 +122,9 @@ def main():
     def time_variant(name, steps, warmup):
         kind, radius, _ = VARIANTS[name]
         n = a.n
-        # ghost depth: the program radius, or 2 for radius-1 programs on several slabs so that the
-        # fused two-step kernel can run with one exchange per pair of steps
-        ghost = 2 if (world > 1 and radius == 1 and kind in ("star", "jacobi7") and n <= 512) else radius
+        # ghost depth: the program radius, or 3 for radius-1 programs on several slabs so that the
+        # fused three-step kernel can run with one exchange per three steps
+        ghost = 3 if (world > 1 and radius == 1 and kind in ("star", "jacobi7")) else radius
         be = HipSlabBackend(n * world, n, n, ghost, rank, world, local_rank)
         be.alloc("p0")
         be.alloc("p1")
@@ -177,7 +177,7 @@ def main():
 
     r = time_variant(a.variant, a.steps, a.warmup)
     value = r["cells_all"] * a.steps / r["dt"] * 1e-9
-    # dominant kernel = the sweep.  One launch advances `steps_per_launch` time steps (2 where the
+    # dominant kernel = the sweep.  One launch advances `steps_per_launch` time steps (3 or 2 where a
     # fused kernel applies, else 1): algorithmic bytes per launch = 8 B x cells x steps per launch,
     # launch duration = HIP-event time over the timed region / launches issued in it.
     # On several GPUs a step is split into boundary-plane and interior launches of the same kernel;

@@ -509,10 +509,10 @@ extern "C" int fdtdx_propagate(fdtdx_ctx *ctx, const char *out, const char *in, 
     return fdtdx_propagate_planes(ctx, out, in, prog, lo, hi, stream);
 }
 
-// Two fused steps out = f(f(in)) with level-1 shell cells taken from `mid` (tb_kernel.h).
-static const TbVariantInfo *pick_tb(const fdtdx_ctx *ctx, const fdtdx_program *prog)
+// Fused steps (tb_kernel.h): out = f^kt(in), kt = 2 or 3, shell cells of the odd levels from `mid`.
+static const TbVariantInfo *pick_tb(const fdtdx_ctx *ctx, const fdtdx_program *prog, int kt)
 {
-    if (!ctx->opt_temporal || ctx->cfg.nprocs != 1 || prog->order != FDTDX_ORDER_CHAIN) return nullptr;
+    if (prog->order != FDTDX_ORDER_CHAIN) return nullptr;
     int ord;
     if (prog->kind == FDTDX_STAR && prog->radius == 1)
         ord = ORD_STAR_CHAIN;
@@ -524,7 +524,7 @@ static const TbVariantInfo *pick_tb(const fdtdx_ctx *ctx, const fdtdx_program *p
     int idx = 0;
     for (int i = 0; i < num_tb_variants(); i++) {
         const TbVariantInfo *v = tb_variant(i);
-        if (v->order != ord) continue;
+        if (v->order != ord || v->kt != kt) continue;
         if (ctx->opt_tb_variant >= 0 ? idx == ctx->opt_tb_variant : !best) best = v;
         idx++;
     }
@@ -544,7 +544,7 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
     p.zg0 = (int)g.first_global, p.nzg = (int)ctx->cfg.Z;
     p.z_lo = (int)z_lo, p.z_hi = (int)z_hi;
     memcpy(p.c, prog->coef, 7 * sizeof(float));
-    const int owned = v->nw * v->ry - 4;
+    const int owned = v->nw * v->ry - 2 * v->kt;
     p.gy = (p.ny - 2 + owned - 1) / owned;
     const int nq = (p.nx + 3) / 4, tq = 64 * v->rx;
     if (nq <= tq)
@@ -555,7 +555,7 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
     long long chunks = ctx->opt_tb_zchunks;
     if (chunks <= 0) {
         // The fused kernel runs one workgroup per CU (registers, LDS), so N workgroups take
-        // ceil(N/256) rounds of the 256 CUs, and every chunk pays for filling its queues (2 planes
+        // ceil(N/256) rounds of the 256 CUs, and every chunk pays for filling its queues (kt planes
         // re-read, plus start-up: about 6 planes' worth in all, from timings at 512^3 and 1024^3):
         // take the chunk count with the best product of the two efficiencies.
         const long long tiles = (long long)p.gx * p.gy;
@@ -563,7 +563,7 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
         chunks = 1;
         for (long long cnt = 1; cnt <= std::max<long long>(1, nz / 16) && cnt * tiles <= 4096; cnt++) {
             const long long len = (nz + cnt - 1) / cnt, n = tiles * ((nz + len - 1) / len);
-            const double eff = (double)n / (double)((n + 255) / 256 * 256) * (double)len / (double)(len + 6);
+            const double eff = (double)n / (double)((n + 255) / 256 * 256) * (double)len / (double)(len + 4 + v->kt);
             if (eff > best + 1e-9) best = eff, chunks = cnt;
         }
     }
@@ -574,35 +574,38 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
     v->launch(p, dim3((unsigned)(p.gx * p.gy * p.gz)), (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     ctx->launches++;
-    snprintf(ctx->last_fused, sizeof(ctx->last_fused), "fused2 kind=%u r=1 waves=%d rows/wave=%d quads/lane/row=%d tile_rows=%d(stored %d) threads=%d lds=%d grid=%dx%dx%d zchunk=%d",
-             prog->kind, v->nw, v->ry, v->rx, v->nw * v->ry, owned, v->threads, v->lds_bytes, p.gx, p.gy, p.gz, p.zchunk);
+    snprintf(ctx->last_fused, sizeof(ctx->last_fused), "fused%d kind=%u r=1 waves=%d rows/wave=%d quads/lane/row=%d tile_rows=%d(stored %d) threads=%d lds=%d grid=%dx%dx%d zchunk=%d",
+             v->kt, prog->kind, v->nw, v->ry, v->rx, v->nw * v->ry, owned, v->threads, v->lds_bytes, p.gx, p.gy, p.gz, p.zchunk);
     return FDTDX_OK;
 }
 
-extern "C" int fdtdx_propagate2_planes(fdtdx_ctx *ctx, const char *out, const char *in, const char *mid, const fdtdx_program *prog,
-                                       uint64_t z_lo, uint64_t z_hi, void *stream)
+extern "C" int fdtdx_propagate_fused_planes(fdtdx_ctx *ctx, const char *out, const char *in, const char *mid, const fdtdx_program *prog,
+                                            uint32_t nsteps, uint64_t z_lo, uint64_t z_hi, void *stream)
 {
     if (!ctx) return fail(FDTDX_ERR_INVALID, "null context");
     int r;
     int rc = check_program(ctx, prog, &r);
     if (rc) return rc;
+    if (nsteps != 2 && nsteps != 3) return fail(FDTDX_ERR_UNSUPPORTED, "fused sweeps advance 2 or 3 steps, not %u", nsteps);
     float *po, *pi, *pm;
     if ((rc = find_cube(ctx, out, &po)) || (rc = find_cube(ctx, in, &pi)) || (rc = find_cube(ctx, mid, &pm))) return rc;
-    if (po == pi || po == pm) return fail(FDTDX_ERR_INVALID, "fused sweep cannot write a cube it reads");
-    const int64_t saved = ctx->opt_temporal;
-    ctx->opt_temporal = 1;
-    const uint32_t np = ctx->cfg.nprocs;
-    ctx->cfg.nprocs = 1;  // pick_tb refuses slabs only because fdtdx_sweep has no exchange; here the caller exchanges
-    const TbVariantInfo *tb = pick_tb(ctx, prog);
-    ctx->cfg.nprocs = np;
-    ctx->opt_temporal = saved;
+    // three steps end on an odd level, whose shell is the one `mid` carries: out may be mid itself
+    // (shell cells are only read, interior cells only written)
+    if (po == pi || pm == pi || (po == pm && nsteps == 2)) return fail(FDTDX_ERR_INVALID, "fused sweep cannot write a cube it reads");
+    const TbVariantInfo *tb = pick_tb(ctx, prog, (int)nsteps);
     if (!tb) return fail(FDTDX_ERR_UNSUPPORTED, "no fused kernel for this program (radius 1, device order only)");
     const fdtdx_geometry &g = ctx->g;
-    // two steps need two planes of support on each side: ghost planes, or the global shell
-    const uint64_t need_lo = g.ghost_lo ? 2 : 1, need_hi = g.ghost_hi ? 2 : 1;
-    if (z_lo < need_lo || z_hi > g.local_planes - need_hi || z_lo > z_hi)
-        return fail(FDTDX_ERR_INVALID, "fused plane range [%llu,%llu) needs 2 ghost planes towards a neighbour", (unsigned long long)z_lo, (unsigned long long)z_hi);
+    // k steps need k planes of support on each side: ghost planes, or the global shell
+    const uint64_t need_lo = g.ghost_lo ? nsteps : 1, need_hi = g.ghost_hi ? nsteps : 1;
+    if ((g.ghost_lo && g.ghost_lo < nsteps) || (g.ghost_hi && g.ghost_hi < nsteps) || z_lo < need_lo || z_hi > g.local_planes - need_hi || z_lo > z_hi)
+        return fail(FDTDX_ERR_INVALID, "fused plane range [%llu,%llu) needs %u ghost planes towards a neighbour", (unsigned long long)z_lo, (unsigned long long)z_hi, nsteps);
     return launch_tb(ctx, tb, po, pi, pm, prog, z_lo, z_hi, stream);
+}
+
+extern "C" int fdtdx_propagate2_planes(fdtdx_ctx *ctx, const char *out, const char *in, const char *mid, const fdtdx_program *prog,
+                                       uint64_t z_lo, uint64_t z_hi, void *stream)
+{
+    return fdtdx_propagate_fused_planes(ctx, out, in, mid, prog, 2, z_lo, z_hi, stream);
 }
 
 extern "C" int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const fdtdx_program *prog, uint32_t steps, void *stream)
@@ -620,13 +623,30 @@ extern "C" int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const f
     if (pa == pb) return fail(FDTDX_ERR_INVALID, "sweep needs two different cubes");
     const fdtdx_geometry &g = ctx->g;
     const uint64_t lo = r, hi = g.local_planes - r;
-    const TbVariantInfo *tb = steps >= 4 ? pick_tb(ctx, prog) : nullptr;
+    // Level t lives in b for even t and in a for odd t (step 0 writes a = f(b)).  The last one to
+    // three steps are always single steps so that a and b end holding exactly the two newest
+    // levels, as after the reference's loop.
+    const int want = (int)ctx->opt_temporal;  // 0 off, 1 auto (deepest), 2 / 3 steps per launch
+    const TbVariantInfo *tb = nullptr;
+    if (steps >= 4 && want != 0) {
+        if (want != 2) tb = pick_tb(ctx, prog, 3);
+        if (!tb && want != 3) tb = pick_tb(ctx, prog, 2);
+    }
     uint32_t done = 0;
-    if (tb) {
-        // Level t lives in b for even t and in a for odd t (step 0 writes a = f(b)).  Fused pairs
-        // hop between b and a third cube c that carries b's shell; a only lends its shell to the
-        // skipped odd levels.  The last one to three steps are single steps so that a and b end
-        // holding exactly the two newest levels, as after the reference's loop.
+    if (tb && tb->kt == 3) {
+        // Three steps per launch hop straight between the two cubes: level t+3 belongs in the
+        // other cube, whose shell is also the one levels t+1 and t+3 see.
+        const uint32_t hops = (steps - 1) / 3;
+        for (uint32_t k = 0; k < hops; k++) {
+            float *out = (done % 2 == 0) ? pa : pb;
+            const float *in = (done % 2 == 0) ? pb : pa;
+            rc = launch_tb(ctx, tb, out, in, out, prog, 1, g.local_planes - 1, stream);
+            if (rc) return rc;
+            done += 3;
+        }
+    } else if (tb) {
+        // Two steps per launch hop between b and a third cube c that carries b's shell; a only
+        // lends its shell to the skipped odd levels.
         uint32_t pairs = (steps % 2 == 0) ? steps / 2 - 1 : ((steps - 1) / 2) & ~1u;
         if (pairs > 0) {
             const size_t bytes = g.cube_elems * sizeof(float);

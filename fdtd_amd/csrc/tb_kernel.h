@@ -111,14 +111,18 @@ __device__ __forceinline__ void level_step(float4 (&res)[RY][RX], const float4 (
     }
 }
 
-template <int NW, int RY, int RX, int ORDER>
-__global__ __launch_bounds__(NW * 64) void tb2_r1_kernel(const TbParams p)
+template <int KT, int NW, int RY, int RX, int ORDER>
+__global__ __launch_bounds__(NW * 64) void tb_r1_kernel(const TbParams p)
 {
-    constexpr int KT = 2;
+    static_assert(KT == 2 || KT == 3, "two or three fused steps");
     constexpr int ROWS = NW * RY;       // rows a tile loads
     constexpr int CYO = ROWS - 2 * KT;  // rows a tile stores
-    // boundary rows exchanged through LDS: [parity][level][wave][side][quad column][lane]
-    __shared__ float4 ex[2][KT][NW][2][RX][64];
+    static_assert(CYO > 0, "tile too small for its overlap");
+    // boundary rows exchanged through LDS: [parity][level][wave][side][quad column][lane].
+    // Two fused steps double-buffer the exchange (one barrier per iteration); three would not fit
+    // in 160 KB that way, so they share one buffer and close every iteration with a second barrier.
+    constexpr int PAR = (KT == 2) ? 2 : 1;
+    __shared__ float4 ex[PAR][KT][NW][2][RX][64];
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -129,8 +133,8 @@ __global__ __launch_bounds__(NW * 64) void tb2_r1_kernel(const TbParams p)
         logical_tile(g, bx, by, bz);
     }
     // Rows wider than one wave's 64*RX quads are cut into x tiles that overlap by one quad on each
-    // side: the outermost quad of a tile only feeds its neighbours' level-1 values (a level-2
-    // cell reaches two cells, i.e. never beyond the adjacent quad) and is stored by the next tile.
+    // side: the outermost quad of a tile only feeds its neighbours' lower-level values (a level-KT
+    // cell reaches KT <= 4 cells, i.e. never beyond the adjacent quad) and is stored by the next tile.
     const int tq0 = p.qbase + bx * p.qstep;
     const bool xtiled = p.gx > 1;
     const int zs = p.z_lo + bz * p.zchunk;
@@ -175,26 +179,32 @@ __global__ __launch_bounds__(NW * 64) void tb2_r1_kernel(const TbParams p)
     const unsigned plane_bytes = (unsigned)(p.plane * 4);
     auto in_rsrc = [&](int z) { return make_rsrc(p.in + (long long)z * p.plane, (z >= 0 && z < p.nz) ? plane_bytes : 0u); };
     auto mid_rsrc = [&](int z) { return make_rsrc(p.mid + (long long)z * p.plane, (z >= 0 && z < p.nz) ? plane_bytes : 0u); };
+    auto zshell = [&](int z) { return (p.zg0 + z <= 0) || (p.zg0 + z >= p.nzg - 1); };  // the whole plane is shell
 
-    // ---- queues: q0 = input planes, q1 = level-1 planes; slot (k + phase) % 3 holds the
-    //      k-th oldest plane -------------------------------------------------------------------
-    float4 q0[3][RY][RX], q1[3][RY][RX], mv[RY][RX];
+    // ---- queues: q[l] = three planes of time level l (l = 0: input).  An iteration that consumes
+    //      input plane pz finds, in the slots named (OLD, MID, NEW) for its phase,
+    //          level 0:      planes pz-2, pz-1, pz
+    //          level l >= 1: a dead plane, planes pz-l-2, pz-l-1
+    //      and every level writes its new plane (level l: plane pz-l; level 0: the load of plane
+    //      pz+1 at the end) into slot OLD, so all queues rotate together by renaming. -------------
+    float4 q[KT][3][RY][RX], mv[RY][RX];
+    const int pz0 = zs - KT + 2;  // first iteration: the first level-1 plane a stored cell depends on is zs-KT+1
     {
-        // first iteration is p = zs: q0 = planes zs-2, zs-1, zs at phase 0
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const __amdgpu_buffer_rsrc_t r = in_rsrc(zs - 2 + k);
+            const __amdgpu_buffer_rsrc_t r = in_rsrc(pz0 - 2 + k);
 #pragma unroll
             for (int j = 0; j < RY; j++)
 #pragma unroll
                 for (int i = 0; i < RX; i++) {
-                    q0[k][j][i] = buf_ld4(r, goff[j][i]);
-                    q1[k][j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    q[0][k][j][i] = buf_ld4(r, goff[j][i]);
+#pragma unroll
+                    for (int l = 1; l < KT; l++) q[l][k][j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
         }
-        // level-1 shell values for plane zs-1
-        const bool zsh = (p.zg0 + zs - 1 <= 0) || (p.zg0 + zs - 1 >= p.nzg - 1);
-        const __amdgpu_buffer_rsrc_t r = mid_rsrc(zs - 1);
+        // level-1 shell values for plane pz0-1
+        const bool zsh = zshell(pz0 - 1);
+        const __amdgpu_buffer_rsrc_t r = mid_rsrc(pz0 - 1);
 #pragma unroll
         for (int j = 0; j < RY; j++)
 #pragma unroll
@@ -203,78 +213,81 @@ __global__ __launch_bounds__(NW * 64) void tb2_r1_kernel(const TbParams p)
 
     const int wu = (w > 0) ? w - 1 : 0, wd = (w < NW - 1) ? w + 1 : NW - 1;
     int par = 0;
-    int pz = zs;  // input plane consumed by the current iteration
-    const int pend = ze + 2;
+    int pz = pz0;  // input plane consumed by the current iteration
+    const int pend = ze + KT;
 
     auto iteration = [&](auto ph) {
         constexpr int PH = decltype(ph)::value;
         constexpr int OLD = PH % 3, MID = (PH + 1) % 3, NEW = (PH + 2) % 3;
-        // publish this wave's first/last rows of the two centre planes (input plane pz-1, level-1 plane pz-2)
+        // publish this wave's first/last rows of every level's centre plane (level 0: input plane
+        // pz-1 in MID; level l: plane pz-l-1 in NEW)
 #pragma unroll
-        for (int i = 0; i < RX; i++) {
-            ex[par][0][w][0][i][lane] = q0[MID][0][i];
-            ex[par][0][w][1][i][lane] = q0[MID][RY - 1][i];
-            ex[par][1][w][0][i][lane] = q1[NEW][0][i];  // q1 slots: MID = plane pz-3, NEW = pz-2, OLD = (dead) pz-4
-            ex[par][1][w][1][i][lane] = q1[NEW][RY - 1][i];
-        }
+        for (int l = 0; l < KT; l++)
+#pragma unroll
+            for (int i = 0; i < RX; i++) {
+                ex[par][l][w][0][i][lane] = q[l][l == 0 ? MID : NEW][0][i];
+                ex[par][l][w][1][i][lane] = q[l][l == 0 ? MID : NEW][RY - 1][i];
+            }
         __syncthreads();
-        float4 up0[RX], dn0[RX], up1[RX], dn1[RX];
+        // ---- levels 1..KT: level l at plane pz-l from level l-1 planes pz-l-1, pz-l, pz-l+1 ------
 #pragma unroll
-        for (int i = 0; i < RX; i++) {
-            up0[i] = ex[par][0][wu][1][i][lane];
-            dn0[i] = ex[par][0][wd][0][i][lane];
-            up1[i] = ex[par][1][wu][1][i][lane];
-            dn1[i] = ex[par][1][wd][0][i][lane];
-        }
-        // ---- level 1 at plane pz-1 from input planes pz-2, pz-1, pz --------------------------
-        {
-            float4 res[RY][RX];
-            level_step<RY, RX, ORDER>(res, q0[OLD], q0[MID], q0[NEW], up0, dn0, c, lane);
-            const bool zsh = (p.zg0 + pz - 1 <= 0) || (p.zg0 + pz - 1 >= p.nzg - 1);  // whole plane is shell
-            // q1 rotates one step behind q0's naming: its OLD slot (plane pz-4) is dead, level-1
-            // plane pz-1 goes there.  With q1 planes (pz-3, pz-2, pz-1) = (MID, NEW, OLD) slots.
+        for (int l = 1; l <= KT; l++) {
+            float4 up[RX], dn[RX], res[RY][RX];
 #pragma unroll
-            for (int j = 0; j < RY; j++)
+            for (int i = 0; i < RX; i++) {
+                up[i] = ex[par][l - 1][wu][1][i][lane];
+                dn[i] = ex[par][l - 1][wd][0][i][lane];
+            }
+            if (l == 1)
+                level_step<RY, RX, ORDER>(res, q[0][OLD], q[0][MID], q[0][NEW], up, dn, c, lane);
+            else
+                level_step<RY, RX, ORDER>(res, q[l - 1][MID], q[l - 1][NEW], q[l - 1][OLD], up, dn, c, lane);
+            // Shell cells keep the value the cube written by that step holds there: level 1 takes
+            // it from `mid`; level l >= 2 finds it in the queue of level l-2, whose plane pz-l has the
+            // same shell (levels of equal parity live in cubes with equal shells).
+            const float4(&sh)[RY][RX] = (l == 1) ? mv : (l == 2) ? q[0][OLD] : q[l >= 3 ? l - 2 : 0][MID];
+            if (l < KT) {
+                const bool zsh = zshell(pz - l);
 #pragma unroll
-                for (int i = 0; i < RX; i++) {
-                    const unsigned m = zsh ? 0u : imask[j][i];
-                    q1[OLD][j][i].x = (m & 1u) ? res[j][i].x : mv[j][i].x;
-                    q1[OLD][j][i].y = (m & 2u) ? res[j][i].y : mv[j][i].y;
-                    q1[OLD][j][i].z = (m & 4u) ? res[j][i].z : mv[j][i].z;
-                    q1[OLD][j][i].w = (m & 8u) ? res[j][i].w : mv[j][i].w;
-                }
-        }
-        // ---- level 2 at plane pz-2 from level-1 planes pz-3 (MID), pz-2 (NEW), pz-1 (OLD) ------
-        {
-            float4 res[RY][RX];
-            level_step<RY, RX, ORDER>(res, q1[MID], q1[NEW], q1[OLD], up1, dn1, c, lane);
-            const bool st = (pz - 2 >= zs) && (pz - 2 < ze);
-            const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.out + (long long)(pz - 2) * p.plane, st ? plane_bytes : 0u);
-            // shell components of a stored quad keep the value `out` holds, which equals the input's
-            // (plane pz-2 is the oldest slot of q0)
+                for (int j = 0; j < RY; j++)
 #pragma unroll
-            for (int j = 0; j < RY; j++)
+                    for (int i = 0; i < RX; i++) {
+                        const unsigned m = zsh ? 0u : imask[j][i];
+                        q[l][OLD][j][i].x = (m & 1u) ? res[j][i].x : sh[j][i].x;
+                        q[l][OLD][j][i].y = (m & 2u) ? res[j][i].y : sh[j][i].y;
+                        q[l][OLD][j][i].z = (m & 4u) ? res[j][i].z : sh[j][i].z;
+                        q[l][OLD][j][i].w = (m & 8u) ? res[j][i].w : sh[j][i].w;
+                    }
+            } else {
+                const bool st = (pz - KT >= zs) && (pz - KT < ze);
+                const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.out + (long long)(pz - KT) * p.plane, st ? plane_bytes : 0u);
 #pragma unroll
-                for (int i = 0; i < RX; i++) {
-                    const unsigned m = imask[j][i];
-                    buf_st4(ro, soff[j][i], (m & 1u) ? res[j][i].x : q0[OLD][j][i].x, (m & 2u) ? res[j][i].y : q0[OLD][j][i].y,
-                            (m & 4u) ? res[j][i].z : q0[OLD][j][i].z, (m & 8u) ? res[j][i].w : q0[OLD][j][i].w);
-                }
+                for (int j = 0; j < RY; j++)
+#pragma unroll
+                    for (int i = 0; i < RX; i++) {
+                        const unsigned m = imask[j][i];
+                        buf_st4(ro, soff[j][i], (m & 1u) ? res[j][i].x : sh[j][i].x, (m & 2u) ? res[j][i].y : sh[j][i].y,
+                                (m & 4u) ? res[j][i].z : sh[j][i].z, (m & 8u) ? res[j][i].w : sh[j][i].w);
+                    }
+            }
         }
         // ---- loads for the next iteration: input plane pz+1 into the dead slot, shell source of plane pz
         {
             const __amdgpu_buffer_rsrc_t rn = in_rsrc((pz + 1 < pend) ? pz + 1 : -1);
-            const bool zshn = (p.zg0 + pz <= 0) || (p.zg0 + pz >= p.nzg - 1);
+            const bool zshn = zshell(pz);
             const __amdgpu_buffer_rsrc_t rm = mid_rsrc((pz + 1 < pend) ? pz : -1);
 #pragma unroll
             for (int j = 0; j < RY; j++)
 #pragma unroll
                 for (int i = 0; i < RX; i++) {
-                    q0[OLD][j][i] = buf_ld4(rn, goff[j][i]);
+                    q[0][OLD][j][i] = buf_ld4(rn, goff[j][i]);
                     mv[j][i] = buf_ld4(rm, zshn ? goff[j][i] : moff[j][i]);
                 }
         }
-        par ^= 1;
+        if constexpr (PAR == 2)
+            par ^= 1;
+        else
+            __syncthreads();  // everyone has read this iteration's rows before the next ones are published
         pz++;
     };
 
@@ -287,6 +300,7 @@ __global__ __launch_bounds__(NW * 64) void tb2_r1_kernel(const TbParams p)
 
 struct TbVariantInfo {
     int order;  // ORD_STAR_CHAIN | ORD_JACOBI_CHAIN
+    int kt;     // fused steps per launch
     int nw, ry, rx, threads, lds_bytes;
     void (*launch)(const TbParams &, dim3 grid, hipStream_t);
 };
@@ -294,27 +308,28 @@ int num_tb_variants();
 const TbVariantInfo *tb_variant(int i);
 void register_tb_variant(const TbVariantInfo &v);
 
-template <int NW, int RY, int RX, int ORDER>
-void tb2_launch(const TbParams &p, dim3 grid, hipStream_t s)
+template <int KT, int NW, int RY, int RX, int ORDER>
+void tb_launch(const TbParams &p, dim3 grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((tb2_r1_kernel<NW, RY, RX, ORDER>), grid, dim3(NW * 64), 0, s, p);
+    hipLaunchKernelGGL((tb_r1_kernel<KT, NW, RY, RX, ORDER>), grid, dim3(NW * 64), 0, s, p);
 }
 
-template <int NW, int RY, int RX, int ORDER>
+template <int KT, int NW, int RY, int RX, int ORDER>
 struct TbRegistrar {
     TbRegistrar()
     {
         TbVariantInfo v;
         v.order = ORDER;
+        v.kt = KT;
         v.nw = NW;
         v.ry = RY;
         v.rx = RX;
         v.threads = NW * 64;
-        v.lds_bytes = 2 * 2 * NW * 2 * RX * 64 * 16;
-        v.launch = &tb2_launch<NW, RY, RX, ORDER>;
+        v.lds_bytes = (KT == 2 ? 2 : 1) * KT * NW * 2 * RX * 64 * 16;
+        v.launch = &tb_launch<KT, NW, RY, RX, ORDER>;
         register_tb_variant(v);
     }
 };
-#define FDTDX_TB_VARIANT(NW, RY, RX, ORDER) static ::fdtdx::TbRegistrar<NW, RY, RX, ORDER> tbreg_##NW##_##RY##_##RX##_##ORDER;
+#define FDTDX_TB_VARIANT(KT, NW, RY, RX, ORDER) static ::fdtdx::TbRegistrar<KT, NW, RY, RX, ORDER> tbreg_##KT##_##NW##_##RY##_##RX##_##ORDER;
 
 }  // namespace fdtdx

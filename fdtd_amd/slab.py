@@ -53,14 +53,16 @@ class HipSlabBackend:
         if z_hi > z_lo:
             self.st.propagatePlanes(out, inp, program, z_lo, z_hi, torch.cuda.current_stream().cuda_stream)
 
-    def sweep2(self, out, inp, mid, program, z_lo, z_hi):
-        """Two fused steps out = f(f(inp)) on planes [z_lo, z_hi) (fdtdx_propagate2_planes)."""
+    def sweep_fused(self, out, inp, mid, program, k, z_lo, z_hi):
+        """k (2 or 3) fused steps out = f^k(inp) on planes [z_lo, z_hi) (fdtdx_propagate_fused_planes)."""
         if z_hi > z_lo:
-            self.st.propagate2Planes(out, inp, mid, program, z_lo, z_hi, torch.cuda.current_stream().cuda_stream)
+            self.st.propagateFusedPlanes(out, inp, mid, program, k, z_lo, z_hi, torch.cuda.current_stream().cuda_stream)
 
     def can_fuse(self, program):
-        return (program.order == _lib.ORDER_CHAIN and program.kind in (_lib.STAR, _lib.JACOBI7)
-                and (program.kind == _lib.JACOBI7 or program.radius == 1))
+        """Deepest fusion the library has a kernel for (0: none)."""
+        ok = (program.order == _lib.ORDER_CHAIN and program.kind in (_lib.STAR, _lib.JACOBI7)
+              and (program.kind == _lib.JACOBI7 or program.radius == 1))
+        return 3 if ok else 0
 
     def copy_cube(self, dst, src):
         self.bufs[dst].copy_(self.bufs[src])
@@ -75,7 +77,8 @@ class SlabRunner:
     def __init__(self, backend, M, program, rank, nprocs, group=None, exchange="device"):
         """exchange: "device" hands the cube's own planes to the process group (RCCL on GPUs, gloo on
         CPU tensors); "host" stages them through CPU tensors (rehearsals of the multi-rank loop on
-        a box whose ranks share one GPU, where RCCL cannot be used)."""
+        a box whose ranks share one GPU, where RCCL cannot be used); "none" skips the exchange
+        (host-cost measurements of the launch sequence only: results are wrong)."""
         self.b, self.M, self.prog = backend, M, program
         self.rank, self.nprocs, self.group = rank, nprocs, group
         self.exchange = exchange
@@ -101,7 +104,7 @@ class SlabRunner:
         return ops
 
     def _start_exchange(self, name):
-        if self.nprocs <= 1:
+        if self.nprocs <= 1 or self.exchange == "none":
             return []
         ops = self._exchange_ops(name)
         if not ops:
@@ -142,36 +145,49 @@ class SlabRunner:
         for r in reqs:
             r.wait()
 
-    def pair(self, out, inp, mid):
-        """Two fused steps out = f(f(inp)) and one exchange of the ghost-depth boundary planes of
-        `out`: half the launches, half the messages (same bytes) of two single steps."""
+    def hop(self, out, inp, mid, k):
+        """k fused steps out = f^k(inp) and one exchange of the ghost-depth boundary planes of
+        `out`: 1/k of the launches and messages (same bytes) of k single steps."""
         G = self.M
         lo, hi = self.z_lo, self.z_hi
         ilo, ihi = lo, hi
         if self.has_lo:
             ilo = min(lo + G, hi)
-            self.b.sweep2(out, inp, mid, self.prog, lo, ilo)
+            self.b.sweep_fused(out, inp, mid, self.prog, k, lo, ilo)
         if self.has_hi:
             ihi = max(hi - G, ilo)
-            self.b.sweep2(out, inp, mid, self.prog, ihi, hi)
+            self.b.sweep_fused(out, inp, mid, self.prog, k, ihi, hi)
         reqs = self._start_exchange(out)
-        self.b.sweep2(out, inp, mid, self.prog, ilo, ihi)
+        self.b.sweep_fused(out, inp, mid, self.prog, k, ilo, ihi)
         for r in reqs:
             r.wait()
 
     def fusable(self):
-        """Two steps per launch need a fused kernel for the program and, towards a neighbour,
-        two ghost planes (context created with M >= 2 for a radius-1 program)."""
+        """Steps per launch this slab can fuse: the deepest fused kernel the backend has for the
+        program, limited towards a neighbour by the ghost depth (context created with M >= 2 or 3
+        for a radius-1 program); 0 if none."""
         can = getattr(self.b, "can_fuse", None)
-        return bool(can and can(self.prog) and self.radius == 1 and (self.M >= 2 or not (self.has_lo or self.has_hi)))
+        k = int(can(self.prog)) if can and self.radius == 1 else 0
+        if self.has_lo or self.has_hi:
+            k = min(k, self.M)
+        return k if k >= 2 else 0
 
     def run(self, a, b, steps, fuse=True):
-        """`steps` ping-pong steps: step 0 writes a = f(b) (fdtd1.cu:68-80).  Where a fused kernel
-        exists the loop hops b -> c -> b two steps at a time (c: a third cube carrying b's shell,
-        a lends its shell to the skipped levels) and ends with 1-3 single steps, so that a and b
-        finish holding the two newest levels exactly as after the step-by-step loop."""
+        """`steps` ping-pong steps: step 0 writes a = f(b) (fdtd1.cu:68-80); level t lives in b for
+        even t, in a for odd t.  Where a fused kernel exists the loop advances three steps per
+        launch straight between the two cubes (level t+3 belongs in the other cube, whose shell is
+        also the one levels t+1 and t+3 see), or, with ghost depth 2, two steps per launch b -> c ->
+        b (c: a third cube carrying b's shell, a lends its shell to the skipped levels).  It always
+        ends with 1-3 single steps, so that a and b finish holding the two newest levels exactly as
+        after the step-by-step loop."""
         done = 0
-        if fuse and steps >= 4 and self.fusable():
+        k = self.fusable() if (fuse and steps >= 4) else 0
+        if k == 3:
+            for _ in range((steps - 1) // 3):
+                out, inp = (a, b) if done % 2 == 0 else (b, a)
+                self.hop(out, inp, out, 3)
+                done += 3
+        elif k == 2:
             pairs = steps // 2 - 1 if steps % 2 == 0 else ((steps - 1) // 2) & ~1
             if pairs > 0:
                 c = "__fused_scratch"
@@ -180,7 +196,7 @@ class SlabRunner:
                 self.b.copy_cube(c, b)
                 cur, oth = b, c
                 for _ in range(pairs):
-                    self.pair(oth, cur, a)
+                    self.hop(oth, cur, a, 2)
                     cur, oth = oth, cur
                 done = 2 * pairs
                 if cur != b:

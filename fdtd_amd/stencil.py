@@ -117,6 +117,13 @@ class Stencil:
         _lib.check(self._L.fdtdx_propagate2_planes(self._h, output.encode(), input.encode(), mid.encode(),
                                                    ctypes.byref(program), z_lo, z_hi, ctypes.c_void_p(stream or 0)))
 
+    def propagateFusedPlanes(self, output, input, mid, program, nsteps, z_lo, z_hi, stream=None):
+        """nsteps (2 or 3) fused steps output = f^nsteps(input) on local planes [z_lo, z_hi); the
+        reference's fused launch is jacobi.cu:446-454 (three steps)."""
+        _lib.check(self._L.fdtdx_propagate_fused_planes(self._h, output.encode(), input.encode(), mid.encode(),
+                                                        ctypes.byref(program), nsteps, z_lo, z_hi,
+                                                        ctypes.c_void_p(stream or 0)))
+
     def sweep(self, a, b, program, steps, stream=None):
         """The drivers' whole time loop on one rank (fdtd1.cu:68-80)."""
         _lib.check(self._L.fdtdx_sweep(self._h, a.encode(), b.encode(), ctypes.byref(program), steps,

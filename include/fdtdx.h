@@ -144,12 +144,21 @@ int fdtdx_propagate_planes(fdtdx_ctx *ctx, const char *out, const char *in, cons
 int fdtdx_propagate_ptr(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx_program *prog,
                         uint64_t z_lo, uint64_t z_hi, void *stream);
 
-/* Two fused time steps restricted to local planes [z_lo, z_hi): out = f(f(in)), the launch
- * jacobi.cu:446-454 issues (temporal_blocking, jacobi.cu:115-400), generalised to cubes whose
- * shells differ: cells of the skipped middle level that lie on the global shell are read from
- * `mid` (the cube a single step would have written), and `out` must already hold the shell of
- * `in`.  Radius-1 programs in device order only (FDTDX_ERR_UNSUPPORTED otherwise).  Towards a
- * neighbouring slab the range needs two ghost planes (create the context with M >= 2). */
+/* Fused time steps restricted to local planes [z_lo, z_hi): out = f^nsteps(in), nsteps = 2 or 3,
+ * the launch jacobi.cu:446-454 issues (temporal_blocking, jacobi.cu:115-400: three steps),
+ * generalised to cubes whose shells differ.  The reference's two cubes keep different shells
+ * (fdtd1.cu:28-29) and step t+1 reads the shell step t's output cube holds, so levels of equal
+ * parity see equal shells: cells of the skipped odd levels that lie on the global shell are read
+ * from `mid` (the cube a single step from `in` would have written), those of the skipped even
+ * level from `in`.  `out` must already hold the shell of its level: that of `in` for nsteps = 2
+ * (out != mid), that of `mid` for nsteps = 3 (out may be `mid` itself: the launch reads only its
+ * shell cells and writes only interior cells).  Radius-1 programs in device order only
+ * (FDTDX_ERR_UNSUPPORTED otherwise).  Towards a neighbouring slab the range needs nsteps ghost
+ * planes (create the context with M >= nsteps). */
+int fdtdx_propagate_fused_planes(fdtdx_ctx *ctx, const char *out, const char *in, const char *mid,
+                                 const fdtdx_program *prog, uint32_t nsteps, uint64_t z_lo, uint64_t z_hi,
+                                 void *stream);
+/* nsteps = 2 */
 int fdtdx_propagate2_planes(fdtdx_ctx *ctx, const char *out, const char *in, const char *mid,
                             const fdtdx_program *prog, uint64_t z_lo, uint64_t z_hi, void *stream);
 
@@ -166,9 +175,9 @@ int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const fdtdx_progra
 int fdtdx_halo_region(fdtdx_ctx *ctx, const char *name, int side, int what, float **ptr, size_t *count);
 
 /* Kernel-selection knobs, for tuning and tests: "zchunks" (z-chunks per sweep launch, 0 = auto),
- * "variant" (tile-shape index, -1 = auto), "temporal" (1 = fdtdx_sweep fuses two time steps per
- * launch where a fused kernel exists, 0 = one launch per step), "tb_variant" / "tb_zchunks" (shape
- * and z-chunks of the fused kernel). */
+ * "variant" (tile-shape index, -1 = auto), "temporal" (time steps fdtdx_sweep fuses per launch where
+ * a fused kernel exists: 1 = as many as there is a kernel for, 2, 3, or 0 = one launch per step),
+ * "tb_variant" / "tb_zchunks" (shape and z-chunks of the fused kernel). */
 int fdtdx_set_option(fdtdx_ctx *ctx, const char *key, int64_t value);
 /* Describes the kernels the last sweeps launched (tile shape, grid, LDS; the last fused launch if
  * any; launches issued so far), for logs and bench. */

@@ -1,7 +1,7 @@
-"""The fused two-step kernel (fdtd_amd/csrc/tb_kernel.h) inside fdtdx_sweep: bit-exact against
-the CPU oracle's step-by-step loop, for every compiled shape, even and odd step counts, grids
-with several y tiles and z chunks, ragged x, and cubes whose two shells differ (the drivers'
-p0/p1 are independent random fields, fdtd1.cu:28-29)."""
+"""The fused kernels (two or three time steps per launch, fdtd_amd/csrc/tb_kernel.h) inside
+fdtdx_sweep: bit-exact against the CPU oracle's step-by-step loop, for every compiled shape,
+step counts of every residue, grids with several y tiles and z chunks, ragged and wide x, and
+cubes whose two shells differ (the drivers' p0/p1 are independent random fields, fdtd1.cu:28-29)."""
 import numpy as np
 import pytest
 
@@ -38,46 +38,54 @@ def run(cpu, kind, shape, steps, tb_variant=-1, tb_zchunks=0, temporal=1):
     return info
 
 
-@pytest.mark.parametrize("steps", [4, 5, 6, 7, 8, 9, 11])
+@pytest.mark.parametrize("steps", [4, 5, 6, 7, 8, 9, 10, 11, 13])
 @pytest.mark.parametrize("kind", ["star", "jacobi7"])
-def test_fused_step_counts(oracle_cpu, kind, steps):
-    info = run(oracle_cpu, kind, (13, 61, 509), steps, tb_zchunks=2)
-    assert "fused2" in info
+@pytest.mark.parametrize("kt", [2, 3])
+def test_fused_step_counts(oracle_cpu, kt, kind, steps):
+    info = run(oracle_cpu, kind, (13, 61, 509), steps, tb_zchunks=2, temporal=kt)
+    assert f"fused{kt}" in info
+
+
+def test_auto_fuses_three_steps(oracle_cpu):
+    assert "fused3" in run(oracle_cpu, "star", (13, 61, 509), 10)
 
 
 @pytest.mark.parametrize("variant", range(5))
 @pytest.mark.parametrize("kind", ["star", "jacobi7"])
 def test_every_fused_shape(oracle_cpu, kind, variant):
-    info = run(oracle_cpu, kind, (21, 75, 512), 6, tb_variant=variant, tb_zchunks=3)
+    info = run(oracle_cpu, kind, (21, 75, 512), 6, tb_variant=variant, tb_zchunks=3, temporal=2)
     assert "fused2" in info
 
 
-@pytest.mark.parametrize("shape", [(3, 3, 3), (5, 7, 9), (9, 20, 21), (40, 19, 300), (7, 130, 64)])
-def test_fused_small_and_ragged(oracle_cpu, shape):
-    run(oracle_cpu, "star", shape, 6)
+@pytest.mark.parametrize("shape", [(3, 3, 3), (5, 7, 9), (9, 20, 21), (40, 19, 300), (7, 130, 64), (31, 9, 40)])
+@pytest.mark.parametrize("kt", [2, 3])
+def test_fused_small_and_ragged(oracle_cpu, kt, shape):
+    run(oracle_cpu, "star", shape, 7, temporal=kt)
 
 
 @pytest.mark.parametrize("X", [513, 700, 1000, 1024, 1531])
 @pytest.mark.parametrize("kind", ["star", "jacobi7"])
-def test_fused_wide_rows_are_cut_into_x_tiles(oracle_cpu, kind, X):
+@pytest.mark.parametrize("kt", [2, 3])
+def test_fused_wide_rows_are_cut_into_x_tiles(oracle_cpu, kt, kind, X):
     """Rows wider than a wave holds (X > 512) are fused too, as x tiles overlapping by one quad."""
-    info = run(oracle_cpu, kind, (9, 30, X), 6)
-    assert "fused2" in info
+    info = run(oracle_cpu, kind, (9, 30, X), 7, temporal=kt)
+    assert f"fused{kt}" in info
 
 
 def test_temporal_off_equals_on(oracle_cpu):
     info = run(oracle_cpu, "star", (12, 40, 256), 8, temporal=0)
-    assert "fused2" not in info
+    assert "fused" not in info
 
 
-@pytest.mark.parametrize("kind,steps", [("star", 8), ("jacobi7", 7)])
-def test_fused_on_two_slabs_equals_one(oracle_cpu, kind, steps):
-    """Fused pairs on a 2-way z split (ghost depth 2, one exchange per pair) on one GPU: the two
-    slabs run in this process and trade ghost planes by device copies.  Equal to the oracle's
-    undecomposed step-by-step result bit for bit."""
+@pytest.mark.parametrize("kind,steps", [("star", 8), ("jacobi7", 7), ("star", 11)])
+@pytest.mark.parametrize("G", [2, 3])
+def test_fused_on_two_slabs_equals_one(oracle_cpu, G, kind, steps):
+    """Fused hops on a 2-way z split (ghost depth G = steps per launch, one exchange per hop) on one
+    GPU: the two slabs run in this process and trade ghost planes by device copies.  Equal to the
+    oracle's undecomposed step-by-step result bit for bit."""
     import torch
     from fdtd_amd.slab import HipSlabBackend, SlabRunner
-    Z, Y, X, G = 48, 75, 512, 2
+    Z, Y, X = 48, 75, 512
     prog = make_program(kind, radius=1)
     if kind == "jacobi7":
         a = oracle_cpu.init_jacobi(Z, Y, X)
@@ -94,7 +102,7 @@ def test_fused_on_two_slabs_equals_one(oracle_cpu, kind, steps):
         be.alloc("c")
         be.copy_cube("c", "p1")
     runs = [SlabRunner(be, G, prog, r, 2) for r, be in enumerate(bes)]
-    assert all(r.fusable() for r in runs)
+    assert all(r.fusable() == G for r in runs)
 
     def exchange(name):
         l0 = runs[0].local
@@ -106,17 +114,27 @@ def test_fused_on_two_slabs_equals_one(oracle_cpu, kind, steps):
             run.b.sweep(out, inp, prog, run.z_lo, run.z_hi)
         exchange(out)
 
-    pairs = steps // 2 - 1 if steps % 2 == 0 else ((steps - 1) // 2) & ~1
-    cur, oth = "p1", "c"
-    for _ in range(pairs):
+    def hop(out, inp, mid):
         for run in runs:
-            run.b.sweep2(oth, cur, "p0", prog, run.z_lo, run.z_hi)
-        exchange(oth)
-        cur, oth = oth, cur
-    done = 2 * pairs
-    if cur != "p1":
-        single("p0", cur)
-        done += 1
+            run.b.sweep_fused(out, inp, mid, prog, G, run.z_lo, run.z_hi)
+        exchange(out)
+
+    done = 0
+    if G == 3:  # the loop of SlabRunner.run, with the exchange done by device copies
+        for _ in range((steps - 1) // 3):
+            out, inp = ("p0", "p1") if done % 2 == 0 else ("p1", "p0")
+            hop(out, inp, out)
+            done += 3
+    else:
+        pairs = steps // 2 - 1 if steps % 2 == 0 else ((steps - 1) // 2) & ~1
+        cur, oth = "p1", "c"
+        for _ in range(pairs):
+            hop(oth, cur, "p0")
+            cur, oth = oth, cur
+        done = 2 * pairs
+        if cur != "p1":
+            single("p0", cur)
+            done += 1
     for t in range(done, steps):
         single("p0", "p1") if t % 2 == 0 else single("p1", "p0")
     torch.cuda.synchronize()

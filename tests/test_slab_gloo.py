@@ -24,7 +24,7 @@ class OracleSlabBackend:
 
     def __init__(self, cpu, Z, Y, X, M, rank, nprocs):
         self.cpu, self.Y, self.X, self.M = cpu, Y, X, M
-        self.Zg, self.fuse = Z, False
+        self.Zg, self.fuse = Z, 0  # fuse: deepest fusion this backend offers
         self.g = lib.decompose(Z, Y, X, M, rank, nprocs)
         self.bufs = {}
 
@@ -52,23 +52,24 @@ class OracleSlabBackend:
         self.cpu.step(kind, dst, src, M=program.radius, order=self.cpu.ORDER_CHAIN, z_lo=z_lo, z_hi=z_hi)
         self.view3(out)[z_lo:z_hi, :, :self.X] = dst[z_lo:z_hi]
 
-    def sweep2(self, out, inp, mid, program, z_lo, z_hi):
-        """Two steps the slow way: level 1 on [z_lo-1, z_hi+1) into a copy of `mid` (which supplies
-        the shell of the skipped level), then level 2 on [z_lo, z_hi)."""
+    def sweep_fused(self, out, inp, mid, program, k, z_lo, z_hi):
+        """k steps the slow way.  Level l is computed on [z_lo-(k-l), z_hi+(k-l)) clipped to the
+        interior planes of the GLOBAL grid, into a copy of the cube whose shell that level sees:
+        `mid` for odd levels, `inp` for even ones, `out` itself for the last."""
         if z_hi <= z_lo:
             return
         kind = {lib.STAR: "star", lib.JACOBI7: "jacobi7"}[program.kind]
         g = self.g
-        src = np.ascontiguousarray(self.view3(inp)[:, :, :self.X])
-        tmp = np.ascontiguousarray(self.view3(mid)[:, :, :self.X])
-        dst = np.ascontiguousarray(self.view3(out)[:, :, :self.X])
-        # level-1 planes that are interior planes of the GLOBAL grid
         gz0, Zg = int(g.first_global), self.Zg
-        l1_lo = max(z_lo - 1, 1 - gz0)
-        l1_hi = min(z_hi + 1, Zg - 1 - gz0)
-        self.cpu.step(kind, tmp, src, M=1, order=self.cpu.ORDER_CHAIN, z_lo=l1_lo, z_hi=l1_hi)
-        self.cpu.step(kind, dst, tmp, M=1, order=self.cpu.ORDER_CHAIN, z_lo=z_lo, z_hi=z_hi)
-        self.view3(out)[z_lo:z_hi, :, :self.X] = dst[z_lo:z_hi]
+        cur = np.ascontiguousarray(self.view3(inp)[:, :, :self.X])
+        for l in range(1, k + 1):
+            shell = out if l == k else (mid if l % 2 == 1 else inp)
+            nxt = np.ascontiguousarray(self.view3(shell)[:, :, :self.X])
+            lo = max(z_lo - (k - l), 1 - gz0)
+            hi = min(z_hi + (k - l), Zg - 1 - gz0)
+            self.cpu.step(kind, nxt, cur, M=1, order=self.cpu.ORDER_CHAIN, z_lo=lo, z_hi=hi)
+            cur = nxt
+        self.view3(out)[z_lo:z_hi, :, :self.X] = cur[z_lo:z_hi]
 
     def can_fuse(self, program):
         return self.fuse
@@ -92,7 +93,7 @@ def _worker(rank, world, port, kind, M, shape, steps, q, ghost=None):
     else:
         a, b = cpu.init_mt(Z, Y, X)
     be = OracleSlabBackend(cpu, Z, Y, X, ghost or M, rank, world)
-    be.fuse = ghost is not None
+    be.fuse = 3 if ghost is not None else 0
     g = be.g
     lo, n = int(g.first_global), int(g.local_planes)
     be.alloc("p0")
@@ -148,18 +149,21 @@ def test_decomposition_invariance(oracle_cpu, world, kind, M, shape, steps):
     assert np.array_equal(got1.view(np.uint32), b.view(np.uint32))
 
 
-@pytest.mark.parametrize("world,kind,shape,steps", [
-    (2, "star", (16, 9, 11), 6),
-    (2, "star", (16, 9, 11), 9),
-    (3, "jacobi7", (23, 8, 10), 8),
-    (2, "star", (14, 7, 9), 11),
+@pytest.mark.parametrize("world,kind,shape,steps,ghost", [
+    (2, "star", (16, 9, 11), 6, 2),
+    (2, "star", (16, 9, 11), 9, 2),
+    (3, "jacobi7", (23, 8, 10), 8, 2),
+    (2, "star", (14, 7, 9), 11, 2),
+    (2, "star", (16, 9, 11), 7, 3),
+    (2, "star", (18, 7, 9), 12, 3),
+    (3, "jacobi7", (26, 8, 10), 11, 3),
 ])
-def test_fused_pairs_on_slabs(oracle_cpu, world, kind, shape, steps):
-    """The two-steps-per-exchange loop (ghost depth 2) equals the undecomposed step-by-step update."""
+def test_fused_hops_on_slabs(oracle_cpu, world, kind, shape, steps, ghost):
+    """Two or three steps per exchange (ghost depth 2 or 3) equal the undecomposed step-by-step update."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, 1, shape, steps, q, 2)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, 1, shape, steps, q, ghost)) for r in range(world)]
     for p in procs:
         p.start()
     parts = [q.get(timeout=120) for _ in range(world)]
