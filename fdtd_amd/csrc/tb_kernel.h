@@ -1,8 +1,9 @@
-// tb_kernel.h -- two fused time steps of a radius-1 sweep (fdtd1.cu / jacobi.cu) in one launch.
+// tb_kernel.h -- two or three fused time steps of a radius-1 sweep (fdtd1.cu / jacobi.cu) in one launch.
 //
 // Counterpart of jacobi.cu's temporal_blocking kernel (jacobi.cu:115-400: 3 fused steps, 32x32
 // blocks, one LDS plane per time level).  Fusing steps is what lowers HBM traffic below one
-// read + one write per cell-update; this kernel moves 8 bytes per cell per TWO updates.
+// read + one write per cell-update; this kernel moves 8 bytes per cell per KT = 2 or 3 updates
+// (plus the rows neighbouring tiles both load).
 //
 // Organisation (different from the single-step kernels on purpose: everything that is reused
 // stays in registers, LDS only carries what crosses a wave):
@@ -15,17 +16,20 @@
 //     per time level).
 //   * z neighbours are register queues of three planes per time level; the z loop is unrolled
 //     three times so that the queues rotate by renaming.
-//   * a workgroup of NW waves covers NW*RY rows; tiles overlap by 2 rows on each side (the rows
-//     whose level-1 / level-2 values would need data outside the tile are recomputed by the
-//     neighbouring tile), so NW*RY-4 rows per tile are stored.
-//   * iteration p consumes input plane p, produces level-1 plane p-1 and stores level-2 plane p-2.
+//   * a workgroup of NW waves covers NW*RY rows; tiles overlap by KT rows on each side (the rows
+//     whose higher-level values would need data outside the tile are recomputed by the
+//     neighbouring tile), so NW*RY-2*KT rows per tile are stored.
+//   * the iteration that consumes input plane p produces level-l plane p-l for l = 1..KT-1 and
+//     stores level-KT plane p-KT.
 //
 // Fixed shell.  The reference never writes the outermost cell layer of either cube, and its two
 // cubes start with DIFFERENT shells (fdtd1.cu:28-29).  After one step the shell a stencil sees
-// is that of the other cube, so the fused kernel takes level-1 shell cells from `mid` (the
-// cube the skipped intermediate step would have written) and leaves the shell of `out`
-// untouched; `out` must already carry the shell of `in` (the caller copies it once).
-// With that the fused launch is bit-identical to two single steps.
+// is that of the other cube, so levels of equal parity see equal shells: the kernel takes the
+// shell cells of odd levels from `mid` (the cube a single step from `in` would write) and those
+// of even levels from `in`, and leaves the shell of `out` untouched.  `out` must already carry the
+// shell of its level: for KT = 2 that of `in` (the caller copies it once into a third cube), for
+// KT = 3 that of `mid`, so a three-step launch can run straight from one of the reference's two
+// cubes into the other (mid == out).  With that a fused launch is bit-identical to KT single steps.
 #pragma once
 #include "sweep_common.h"
 
