@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--variant", default="jacobi", choices=sorted(VARIANTS))
     ap.add_argument("--size", dest="n", type=int, default=512, help="slab edge: every GPU owns n planes of n x n cells")
+    ap.add_argument("--temporal", type=int, default=1,
+                    help="time steps fused per launch where a fused kernel exists: 1 = deepest (default), 2, 3, 0 = none")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--all-variants", action="store_true", help="also time every other variant (N=1 only)")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
@@ -134,6 +136,7 @@ def main():
         else:
             be.st.initMt("p0", "p1")
         prog = make_program(kind, radius=radius)
+        be.st.setOption("temporal", a.temporal)
         run = SlabRunner(be, ghost, prog, rank, world, exchange="host" if a.rehearse_shared_gpu else "device")
         cs = torch.cuda.current_stream().cuda_stream
 
@@ -143,7 +146,7 @@ def main():
                 # loop of fdtd1.cu:68-80), which fuses two steps per launch where it can
                 be.st.sweep("p0", "p1", prog, k, cs)
             else:
-                run.run("p0", "p1", k)
+                run.run("p0", "p1", k, fuse=a.temporal != 0)
 
         def launches():
             return int(be.st.lastLaunchInfo().rsplit("launches=", 1)[1])
@@ -190,7 +193,8 @@ def main():
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
         try:
-            traffic = json.load(open(tf)).get(f"{a.variant}_n{a.n}", {}).get("hbm_bytes_per_launch")
+            key = a.variant + ("_singlestep" if a.temporal == 0 and VARIANTS[a.variant][1] == 1 and a.variant != "fdtdspc" else "")
+            traffic = json.load(open(tf)).get(f"{key}_n{a.n}", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
