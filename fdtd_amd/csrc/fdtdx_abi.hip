@@ -373,7 +373,7 @@ static int check_program(const fdtdx_ctx *ctx, const fdtdx_program *prog, int *r
 static void default_shape(int kind, int r, int nq, int *tq, int *ly, int *ry)
 {
     if (kind == FDTDX_SPC13) {
-        *tq = 64, *ly = 4, *ry = 2;
+        *tq = 64, *ly = 8, *ry = 2;
         return;
     }
     if (r <= 4) {

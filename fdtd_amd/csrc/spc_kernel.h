@@ -4,7 +4,8 @@
 // loads per cell.  Here a workgroup keeps planes z-1, z, z+1 of its tile (plus a one-cell halo
 // INCLUDING corners, because the stencil has in-plane and cross-plane diagonals) in a ring of
 // four LDS plane images; each plane is read from HBM once per tile with coalesced 16-byte loads
-// and every neighbour, diagonal or not, is an LDS read.  Four ring slots let the loads of
+// and every neighbour quad, diagonal or not, is an LDS read (the single cells left/right of a quad
+// come from the neighbouring lanes' registers by DPP).  Four ring slots let the loads of
 // plane z+2 land while plane z is being computed with a single barrier per plane.  Global traffic
 // uses raw buffer loads/stores with out-of-range offsets as lane masks (no divergent branches in
 // the z loop, counted waits), exactly as in star_kernel.h.
@@ -12,6 +13,15 @@
 #include "sweep_common.h"
 
 namespace fdtdx {
+
+__device__ __forceinline__ float lane_from_prev(float v)  // lane l receives lane l-1 (lane 0: lane 63)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_from_next(float v)  // lane l receives lane l+1 (lane 63: lane 0)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x134, 0xF, 0xF, false));
+}
 
 template <int TQ, int LY, int RY, int GOLDEN>
 __global__ __launch_bounds__(TQ *LY) void spc13_sweep_kernel(const SweepParams p)
@@ -29,6 +39,9 @@ __global__ __launch_bounds__(TQ *LY) void spc13_sweep_kernel(const SweepParams p
 
     const int t = threadIdx.x;
     const int tx = t % TQ, ty = t / TQ;
+    // lanes whose left / right neighbour quad is not held by the previous / next lane of the wave
+    const bool first_in_run = (tx == 0) || ((t & 63) == 0);
+    const bool last_in_run = (tx == TQ - 1) || ((t & 63) == 63);
     int bx, by, bz;
     logical_tile(p, bx, by, bz);
     const int q0 = bx * TQ;
@@ -146,15 +159,25 @@ __global__ __launch_bounds__(TQ *LY) void spc13_sweep_kernel(const SweepParams p
         for (int j = 0; j < RY; j++) {
             const int o = ownl[j];
             const float4 C = s0[o];
-            const float Lw = reinterpret_cast<const float *>(s0 + o - 1)[3];
-            const float Rx = reinterpret_cast<const float *>(s0 + o + 1)[0];
             const float4 U = s0[o + LPQ], D = s0[o - LPQ];
-            const float URx = reinterpret_cast<const float *>(s0 + o + LPQ + 1)[0];
-            const float DLw = reinterpret_cast<const float *>(s0 + o - LPQ - 1)[3];
             const float4 ZP = sp[o], ZM = sm[o];
             const float4 ZPU = sp[o + LPQ], ZMD = sm[o - LPQ];
-            const float ZPURx = reinterpret_cast<const float *>(sp + o + LPQ + 1)[0];
-            const float ZMDLw = reinterpret_cast<const float *>(sm + o - LPQ - 1)[3];
+            // The six single cells left/right of those quads belong to the neighbouring lanes'
+            // quads: take them from their registers with a DPP wave rotate.  (Read from LDS, 4-byte
+            // reads at a 16-byte lane stride are 4-way bank conflicts.)  Only the lanes at the end of
+            // a wave or of a tile row have no such neighbour and read LDS, a few lanes at a time.
+            float Lw = lane_from_prev(C.w), DLw = lane_from_prev(D.w), ZMDLw = lane_from_prev(ZMD.w);
+            float Rx = lane_from_next(C.x), URx = lane_from_next(U.x), ZPURx = lane_from_next(ZPU.x);
+            if (first_in_run) {
+                Lw = reinterpret_cast<const float *>(s0 + o - 1)[3];
+                DLw = reinterpret_cast<const float *>(s0 + o - LPQ - 1)[3];
+                ZMDLw = reinterpret_cast<const float *>(sm + o - LPQ - 1)[3];
+            }
+            if (last_in_run) {
+                Rx = reinterpret_cast<const float *>(s0 + o + 1)[0];
+                URx = reinterpret_cast<const float *>(s0 + o + LPQ + 1)[0];
+                ZPURx = reinterpret_cast<const float *>(sp + o + LPQ + 1)[0];
+            }
 
             const float cv[4] = {C.x, C.y, C.z, C.w};
             const float xp[4] = {C.y, C.z, C.w, Rx}, xm[4] = {Lw, C.x, C.y, C.z};
