@@ -102,6 +102,18 @@ public:
         (void)spill;
         FDTDX_ASSERT(fdtdx_propagate(ctx_, output.c_str(), input.c_str(), &prog, stream));
     }
+    // propagateHalo{Top,Buttom}Backup (stencil.h:770-808): one step on local planes [z_lo, z_hi) only
+    void propagatePlanes(const std::string &output, const std::string &input, const fdtdx_program &prog, uint64_t z_lo, uint64_t z_hi,
+                         void *stream = nullptr)
+    {
+        FDTDX_ASSERT(fdtdx_propagate_planes(ctx_, output.c_str(), input.c_str(), &prog, z_lo, z_hi, stream));
+    }
+    // one fused launch of nsteps = 2 or 3 steps on local planes [z_lo, z_hi) (jacobi.cu:446-454)
+    void propagateFusedPlanes(const std::string &output, const std::string &input, const std::string &mid, const fdtdx_program &prog,
+                              unsigned nsteps, uint64_t z_lo, uint64_t z_hi, void *stream = nullptr)
+    {
+        FDTDX_ASSERT(fdtdx_propagate_fused_planes(ctx_, output.c_str(), input.c_str(), mid.c_str(), &prog, nsteps, z_lo, z_hi, stream));
+    }
     // the drivers' whole loop on one rank (fdtd1.cu:68-80): `steps` ping-pong steps, step 0 writes a = f(b)
     void sweep(const std::string &a, const std::string &b, const fdtdx_program &prog, unsigned steps, void *stream = nullptr)
     {
