@@ -8,7 +8,7 @@ machinery of stencil.h:639-682 / 770-808:
   backupCubeHaloBackup   D2D 3M planes x2       --  (ghost planes live inside the cube)
   propagateHalo{Top,Buttom}Backup (M planes)    sweep the M boundary planes next to each face
   sync; propagate (whole slab, async)           start isend/irecv of those planes (RCCL stream)
-  commCubeHaloBackup     host-blocking MPI      sweep the interior planes (compute stream)
+  commCubeHaloBackup     host-blocking MPI      sweep the interior planes (compute stream, concurrently)
   sync; restoreCubeHaloBackup D2D x2; sync      wait for the exchange; swap
 
 The boundary planes are written once (not twice as in the reference) and are received
@@ -38,6 +38,22 @@ class HipSlabBackend:
         self.st = Stencil(Z, Y, X, M, rank=rank, nprocs=nprocs, device=device)
         self.g = self.st.geometry
         self.bufs = {}
+        # optional second stream for the boundary-plane sweeps (SlabRunner(side_stream=True))
+        self.side = torch.cuda.Stream(self.device)
+
+    def fork_side(self):
+        """Work issued on the side stream from here on sees everything queued on the main stream so far."""
+        self.side.wait_stream(torch.cuda.current_stream())
+
+    def join_side(self):
+        """Work issued on the main stream from here on sees everything queued on the side stream so far."""
+        torch.cuda.current_stream().wait_stream(self.side)
+
+    def side_ctx(self):
+        return torch.cuda.stream(self.side)
+
+    def _stream(self, side):
+        return self.side.cuda_stream if side else torch.cuda.current_stream().cuda_stream
 
     def alloc(self, name):
         t = torch.zeros(int(self.g.cube_elems), dtype=torch.float32, device=self.device)
@@ -49,14 +65,14 @@ class HipSlabBackend:
         p = int(self.g.plane)
         return self.bufs[name][first * p:(first + count) * p]
 
-    def sweep(self, out, inp, program, z_lo, z_hi):
+    def sweep(self, out, inp, program, z_lo, z_hi, side=False):
         if z_hi > z_lo:
-            self.st.propagatePlanes(out, inp, program, z_lo, z_hi, torch.cuda.current_stream().cuda_stream)
+            self.st.propagatePlanes(out, inp, program, z_lo, z_hi, self._stream(side))
 
-    def sweep_fused(self, out, inp, mid, program, k, z_lo, z_hi):
+    def sweep_fused(self, out, inp, mid, program, k, z_lo, z_hi, side=False):
         """k (2 or 3) fused steps out = f^k(inp) on planes [z_lo, z_hi) (fdtdx_propagate_fused_planes)."""
         if z_hi > z_lo:
-            self.st.propagateFusedPlanes(out, inp, mid, program, k, z_lo, z_hi, torch.cuda.current_stream().cuda_stream)
+            self.st.propagateFusedPlanes(out, inp, mid, program, k, z_lo, z_hi, self._stream(side))
 
     def can_fuse(self, program):
         """Deepest fusion the library has a kernel for (0: none)."""
@@ -74,7 +90,7 @@ class HipSlabBackend:
 class SlabRunner:
     """The time loop of one rank.  `backend` provides alloc/planes/sweep/synchronize and `.g`."""
 
-    def __init__(self, backend, M, program, rank, nprocs, group=None, exchange="device"):
+    def __init__(self, backend, M, program, rank, nprocs, group=None, exchange="device", side_stream=None):
         """exchange: "device" hands the cube's own planes to the process group (RCCL on GPUs, gloo on
         CPU tensors); "host" stages them through CPU tensors (rehearsals of the multi-rank loop on
         a box whose ranks share one GPU, where RCCL cannot be used); "none" skips the exchange
@@ -82,6 +98,10 @@ class SlabRunner:
         self.b, self.M, self.prog = backend, M, program
         self.rank, self.nprocs, self.group = rank, nprocs, group
         self.exchange = exchange
+        # True: boundary launches and the exchange go to a second stream beside the interior sweep.
+        # Measured slower on MI355X (the boundary launches are short, the stream hand-overs are not:
+        # 114 vs 111 us per step for the fused jacobi loop at 512^3), so off unless asked for.
+        self.side_stream = bool(side_stream)
         g = backend.g
         self.local = int(g.local_planes)
         self.has_lo = int(g.ghost_lo) > 0
@@ -129,38 +149,44 @@ class SlabRunner:
                     t.copy_(h)
         return [_Staged()]
 
-    def step(self, out, inp):
-        """out = f(inp) on the owned planes, then out's ghost planes = neighbours' new boundary planes."""
-        M = self.M
+    def _split(self, sweep):
+        """One update of the owned planes as boundary-first launches: `sweep(z_lo, z_hi, side)` is
+        called for the ghost-depth planes next to each neighbour, then the exchange of those planes
+        starts behind them, then the interior runs beside the exchange."""
+        G = self.M
         lo, hi = self.z_lo, self.z_hi
         ilo, ihi = lo, hi
-        if self.has_lo:  # the M planes the lower neighbour needs
-            ilo = min(lo + M, hi)
-            self.b.sweep(out, inp, self.prog, lo, ilo)
+        b = self.b
+        two = self.side_stream and (self.has_lo or self.has_hi) and hasattr(b, "fork_side")
+        if two:
+            b.fork_side()
+        if self.has_lo:
+            ilo = min(lo + G, hi)
+            sweep(lo, ilo, two)
         if self.has_hi:
-            ihi = max(hi - M, ilo)
-            self.b.sweep(out, inp, self.prog, ihi, hi)
-        reqs = self._start_exchange(out)
-        self.b.sweep(out, inp, self.prog, ilo, ihi)
+            ihi = max(hi - G, ilo)
+            sweep(ihi, hi, two)
+        if two:
+            with b.side_ctx():
+                reqs = self._start_exchange(self._out)
+        else:
+            reqs = self._start_exchange(self._out)
+        sweep(ilo, ihi, False)
+        if two:
+            b.join_side()
         for r in reqs:
             r.wait()
+
+    def step(self, out, inp):
+        """out = f(inp) on the owned planes, then out's ghost planes = neighbours' new boundary planes."""
+        self._out = out
+        self._split(lambda z0, z1, side: self.b.sweep(out, inp, self.prog, z0, z1, **({"side": True} if side else {})))
 
     def hop(self, out, inp, mid, k):
         """k fused steps out = f^k(inp) and one exchange of the ghost-depth boundary planes of
         `out`: 1/k of the launches and messages (same bytes) of k single steps."""
-        G = self.M
-        lo, hi = self.z_lo, self.z_hi
-        ilo, ihi = lo, hi
-        if self.has_lo:
-            ilo = min(lo + G, hi)
-            self.b.sweep_fused(out, inp, mid, self.prog, k, lo, ilo)
-        if self.has_hi:
-            ihi = max(hi - G, ilo)
-            self.b.sweep_fused(out, inp, mid, self.prog, k, ihi, hi)
-        reqs = self._start_exchange(out)
-        self.b.sweep_fused(out, inp, mid, self.prog, k, ilo, ihi)
-        for r in reqs:
-            r.wait()
+        self._out = out
+        self._split(lambda z0, z1, side: self.b.sweep_fused(out, inp, mid, self.prog, k, z0, z1, **({"side": True} if side else {})))
 
     def fusable(self):
         """Steps per launch this slab can fuse: the deepest fused kernel the backend has for the

@@ -23,7 +23,7 @@ for name, kind, radius in (("jacobi", "jacobi7", 1), ("fdtd1", "star", 1), ("fdt
     be.alloc("p0")
     be.alloc("p1")
     prog = make_program(kind, radius=radius)
-    run = SlabRunner(be, ghost, prog, 1, 3, exchange="none")
+    run = SlabRunner(be, ghost, prog, 1, 3, exchange="none", side_stream=os.environ.get("SIDE", "") == "1")
     run.run("p0", "p1", 10)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
