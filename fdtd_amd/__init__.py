@@ -4,6 +4,6 @@
   stencil  `Stencil`: Python face of the reference's host class, same method names
   slab     z-slab time loop with ghost-plane exchange over torch.distributed (RCCL / gloo)
 """
-from .lib import (FdtdxError, make_program, decompose, STAR, SPC13, JACOBI7, ORDER_CHAIN,  # noqa: F401
+from .lib import (FdtdxError, make_program, make_composite, decompose, STAR, SPC13, JACOBI7, ORDER_CHAIN,  # noqa: F401
                   ORDER_GOLDEN)
 from .stencil import Stencil  # noqa: F401

@@ -79,6 +79,11 @@ struct fdtdx_ctx {
     fdtdx_geometry g;
     int device = 0;
     std::map<std::string, Cube> pool;  // memoryPool of stencil.h:361
+    struct AddrList {
+        uint64_t *ptr = nullptr;
+        size_t capacity = 0, count = 0;
+    };
+    std::map<std::string, AddrList> addr;  // address lists (stencil.h:363: addrLen)
     int64_t opt_zchunks = 0;           // 0 = auto
     int64_t opt_variant = -1;          // -1 = auto
     int64_t opt_temporal = 1;          // fuse two steps per launch where a fused kernel exists
@@ -159,6 +164,8 @@ extern "C" int fdtdx_destroy(fdtdx_ctx *ctx)
     for (auto &kv : ctx->pool)
         if (kv.second.owned && kv.second.ptr && hipFree(kv.second.ptr) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(%s) failed", kv.first.c_str());
     if (ctx->tb_scratch && hipFree(ctx->tb_scratch) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(scratch) failed");
+    for (auto &kv : ctx->addr)
+        if (kv.second.ptr && hipFree(kv.second.ptr) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(%s) failed", kv.first.c_str());
     delete ctx;
     return rc;
 }
@@ -393,10 +400,19 @@ static void default_shape(int kind, int r, int nq, int *tq, int *ly, int *ry)
     }
 }
 
-static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx_program *prog, uint64_t z_lo, uint64_t z_hi, void *stream)
+static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx_program *prog, uint64_t z_lo, uint64_t z_hi, void *stream,
+                        const fdtdx_composite *comp = nullptr, const float *vel = nullptr)
 {
     int r;
-    int rc = check_program(ctx, prog, &r);
+    int rc;
+    fdtdx_program cprog;
+    if (comp) {  // composite update: the star machinery with another per-cell formula
+        if (comp->radius < 1 || comp->radius > 8) return fail(FDTDX_ERR_UNSUPPORTED, "composite radius %u outside 1..8", comp->radius);
+        memset(&cprog, 0, sizeof(cprog));
+        cprog.kind = FDTDX_STAR, cprog.radius = comp->radius, cprog.order = comp->order;
+        prog = &cprog;
+    }
+    rc = check_program(ctx, prog, &r);
     if (rc) return rc;
     const fdtdx_geometry &g = ctx->g;
     if (z_lo < (uint64_t)r || z_hi > g.local_planes - r || z_lo > z_hi)
@@ -417,6 +433,13 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
     p.z_hi = (int)z_hi;
     memset(p.c, 0, sizeof(p.c));
     memcpy(p.c, prog->coef, 13 * sizeof(float));
+    p.vel = vel;
+    p.zg0 = (int)g.first_global;
+    memset(p.kd, 0, sizeof(p.kd));
+    if (comp) {
+        const double kd[8] = {comp->cz, comp->cy, comp->cx, comp->scal_num, comp->scal_den, comp->wx, comp->wy, comp->wz};
+        memcpy(p.kd, kd, sizeof(kd));
+    }
 
     int tq, ly, ry, threads, lds, pf = 1;
     void (*launch)(const SweepParams &, dim3, hipStream_t) = nullptr;
@@ -434,8 +457,9 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
         if (!best) return fail(FDTDX_ERR_UNSUPPORTED, "no spc13 kernel for order %u", prog->order);
         tq = best->tq, ly = best->ly, ry = best->ry, threads = best->threads, lds = best->lds_bytes, launch = best->launch;
     } else {
-        int ord = (prog->kind == FDTDX_STAR) ? (prog->order == FDTDX_ORDER_CHAIN ? ORD_STAR_CHAIN : ORD_STAR_GOLDEN)
-                                             : (prog->order == FDTDX_ORDER_CHAIN ? ORD_JACOBI_CHAIN : ORD_JACOBI_GOLDEN);
+        int ord = comp ? (prog->order == FDTDX_ORDER_CHAIN ? ORD_COMP_CHAIN : ORD_COMP_GOLDEN)
+                  : (prog->kind == FDTDX_STAR) ? (prog->order == FDTDX_ORDER_CHAIN ? ORD_STAR_CHAIN : ORD_STAR_GOLDEN)
+                                               : (prog->order == FDTDX_ORDER_CHAIN ? ORD_JACOBI_CHAIN : ORD_JACOBI_GOLDEN);
         const VariantInfo *best = nullptr;
         int idx = 0;
         for (int i = 0; i < num_variants(); i++) {
@@ -674,6 +698,184 @@ extern "C" int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const f
         const float *in = (t % 2 == 0) ? pb : pa;
         rc = launch_sweep(ctx, out, in, prog, lo, hi, stream);
         if (rc) return rc;
+    }
+    return FDTDX_OK;
+}
+
+// ---- the composite pipeline of main.cu: sweep, inject, filt, mul ---------------------------------------
+static int owned_range(const fdtdx_ctx *ctx, uint64_t z_lo, uint64_t z_hi, const char *what)
+{
+    const fdtdx_geometry &g = ctx->g;
+    if (z_lo > z_hi || z_hi > g.local_planes) return fail(FDTDX_ERR_INVALID, "%s: plane range [%llu,%llu) outside the local cube", what, (unsigned long long)z_lo, (unsigned long long)z_hi);
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_propagate_composite_planes(fdtdx_ctx *ctx, const char *out, const char *in, const char *vel, const fdtdx_composite *comp,
+                                                uint64_t z_lo, uint64_t z_hi, void *stream)
+{
+    if (!ctx || !comp) return fail(FDTDX_ERR_INVALID, "null argument");
+    float *po, *pi, *pv;
+    int rc;
+    if ((rc = find_cube(ctx, out, &po)) || (rc = find_cube(ctx, in, &pi)) || (rc = find_cube(ctx, vel, &pv))) return rc;
+    if (po == pv) return fail(FDTDX_ERR_INVALID, "the composite update cannot write its velocity cube");
+    if (comp->scal_den == 0.0) return fail(FDTDX_ERR_INVALID, "scal_den is zero");
+    return launch_sweep(ctx, po, pi, nullptr, z_lo, z_hi, stream, comp, pv);
+}
+
+extern "C" int fdtdx_propagate_composite(fdtdx_ctx *ctx, const char *out, const char *in, const char *vel, const fdtdx_composite *comp, void *stream)
+{
+    if (!ctx || !comp) return fail(FDTDX_ERR_INVALID, "null argument");
+    const fdtdx_geometry &g = ctx->g;
+    const uint64_t r = comp->radius;
+    const uint64_t lo = g.ghost_lo ? g.ghost_lo : r;
+    const uint64_t hi = g.ghost_hi ? g.local_planes - g.ghost_hi : g.local_planes - r;
+    return fdtdx_propagate_composite_planes(ctx, out, in, vel, comp, lo, hi, stream);
+}
+
+extern "C" int fdtdx_malloc_addr(fdtdx_ctx *ctx, const char *name, uint64_t capacity)
+{
+    if (!ctx || !name) return fail(FDTDX_ERR_INVALID, "null argument");
+    if (ctx->addr.count(name)) return fail(FDTDX_ERR_EXISTS, "address list '%s' exists (stencil.h:443)", name);
+    fdtdx_ctx::AddrList a;
+    a.capacity = capacity;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (capacity) HIP_TRY(hipMalloc((void **)&a.ptr, capacity * sizeof(uint64_t)));
+    ctx->addr[name] = a;
+    return FDTDX_OK;
+}
+
+// stencil.h:518-544: keep the addresses whose plane this rank owns and re-base them to the local padded cube
+extern "C" int fdtdx_transfer_addr_to_gpu(fdtdx_ctx *ctx, const char *name, const uint64_t *global_addr, uint64_t n)
+{
+    if (!ctx || !name || (!global_addr && n)) return fail(FDTDX_ERR_INVALID, "null argument");
+    auto it = ctx->addr.find(name);
+    if (it == ctx->addr.end()) return fail(FDTDX_ERR_NOTFOUND, "no address list '%s'", name);
+    const fdtdx_geometry &g = ctx->g;
+    const uint64_t X = ctx->cfg.X, Y = ctx->cfg.Y, Z = ctx->cfg.Z;
+    std::vector<uint64_t> local;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint64_t a = global_addr[i];
+        const uint64_t z = a / (Y * X), y = (a % (Y * X)) / X, x = a % X;
+        if (z >= Z) return fail(FDTDX_ERR_INVALID, "address %llu outside the grid", (unsigned long long)a);
+        if (z < g.owned_begin || z >= g.owned_begin + g.owned_planes) continue;
+        local.push_back((z - g.first_global) * g.plane + y * g.pitch_x + x);
+    }
+    if (local.size() > it->second.capacity) return fail(FDTDX_ERR_INVALID, "%zu addresses exceed the capacity %zu of '%s'", local.size(), it->second.capacity, name);
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!local.empty()) HIP_TRY(hipMemcpy(it->second.ptr, local.data(), local.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    it->second.count = local.size();
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_addr_size(fdtdx_ctx *ctx, const char *name, uint64_t *count)
+{
+    if (!ctx || !name || !count) return fail(FDTDX_ERR_INVALID, "null argument");
+    auto it = ctx->addr.find(name);
+    *count = (it == ctx->addr.end()) ? 0 : it->second.count;  // getAddrSize (stencil.h:500-504): 0 for an unknown name
+    return FDTDX_OK;
+}
+
+__global__ void inject_planes_kernel(float *cube, const uint64_t *addr, uint64_t n, float add, uint64_t plane, uint64_t z_lo, uint64_t z_hi)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t a = addr[i], z = a / plane;
+    if (z >= z_lo && z < z_hi) atomicAdd(cube + a, add);
+}
+
+extern "C" int fdtdx_inject(fdtdx_ctx *ctx, const char *cube, const char *addr_name, float add, uint64_t z_lo, uint64_t z_hi, void *stream)
+{
+    float *pc;
+    int rc = find_cube(ctx, cube, &pc);
+    if (rc) return rc;
+    if (!addr_name) return fail(FDTDX_ERR_INVALID, "null argument");
+    if ((rc = owned_range(ctx, z_lo, z_hi, "inject"))) return rc;
+    auto it = ctx->addr.find(addr_name);
+    if (it == ctx->addr.end()) return fail(FDTDX_ERR_NOTFOUND, "no address list '%s'", addr_name);
+    const uint64_t n = it->second.count;
+    if (n == 0 || z_lo == z_hi) return FDTDX_OK;
+    hipLaunchKernelGGL(inject_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pc, it->second.ptr, n, add,
+                       ctx->g.plane, z_lo, z_hi);
+    HIP_TRY(hipGetLastError());
+    return FDTDX_OK;
+}
+
+// one wave per row (z, y): the whole row if the plane or the row is selected, else the single selected cell
+__global__ void filt_planes_kernel(float *cube, long long plane, int px, int nx, int ny, long long zg0, long long z_lo, long long nrows,
+                                   long long zsel, long long ysel, long long xsel, double scale, int golden)
+{
+    const long long row = (long long)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int lane = threadIdx.x & 63;
+    const long long z = z_lo + row / ny;
+    const int y = (int)(row % ny);
+    float *r = cube + z * plane + (long long)y * px;
+    const float sf = (float)scale;
+    if (zg0 + z == zsel || y == ysel) {
+        for (int x = lane; x < nx; x += 64) r[x] = golden ? (float)((double)r[x] * scale) : r[x] * sf;
+    } else if (lane == 0 && xsel >= 0 && xsel < nx) {
+        r[xsel] = golden ? (float)((double)r[xsel] * scale) : r[xsel] * sf;
+    }
+}
+
+extern "C" int fdtdx_filt_planes(fdtdx_ctx *ctx, const char *cube, int64_t zsel, int64_t ysel, int64_t xsel, double scale, uint32_t order,
+                                 uint64_t z_lo, uint64_t z_hi, void *stream)
+{
+    float *pc;
+    int rc = find_cube(ctx, cube, &pc);
+    if (rc) return rc;
+    if ((rc = owned_range(ctx, z_lo, z_hi, "filt"))) return rc;
+    if (order != FDTDX_ORDER_CHAIN && order != FDTDX_ORDER_GOLDEN) return fail(FDTDX_ERR_INVALID, "unknown order %u", order);
+    if (z_lo == z_hi) return FDTDX_OK;
+    const fdtdx_geometry &g = ctx->g;
+    const long long nrows = (long long)(z_hi - z_lo) * (long long)ctx->cfg.Y;
+    const long long blocks = (nrows + 3) / 4;
+    if (blocks > 0x7fffffffLL) return fail(FDTDX_ERR_UNSUPPORTED, "grid too large");
+    hipLaunchKernelGGL(filt_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pc, (long long)g.plane, (int)g.pitch_x,
+                       (int)ctx->cfg.X, (int)ctx->cfg.Y, (long long)g.first_global, (long long)z_lo, nrows, (long long)zsel, (long long)ysel,
+                       (long long)xsel, scale, order == FDTDX_ORDER_GOLDEN ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return FDTDX_OK;
+}
+
+// sum += a*b on the interior: one quad per lane; grid = (quad blocks, interior rows, planes)
+__global__ void mul_acc_kernel(float *sum, const float *a, const float *b, long long plane, int px, int nx, int h, long long z_lo, int golden)
+{
+    const long long z = z_lo + blockIdx.z;
+    const int y = h + (int)blockIdx.y;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x0 = 4 * q;
+    if (x0 >= nx - h || x0 + 3 < h) return;
+    const long long off = z * plane + (long long)y * px + x0;
+    const float4 s = *reinterpret_cast<const float4 *>(sum + off);
+    const float4 va = *reinterpret_cast<const float4 *>(a + off), vb = *reinterpret_cast<const float4 *>(b + off);
+    float sv[4] = {s.x, s.y, s.z, s.w};
+    const float av[4] = {va.x, va.y, va.z, va.w}, bv[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (x0 + i >= h && x0 + i < nx - h) sv[i] = golden ? sv[i] + av[i] * bv[i] : __builtin_fmaf(av[i], bv[i], sv[i]);
+    *reinterpret_cast<float4 *>(sum + off) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+}
+
+extern "C" int fdtdx_mul_acc(fdtdx_ctx *ctx, const char *sum, const char *a, const char *b, uint32_t radius, uint32_t order, uint64_t z_lo,
+                             uint64_t z_hi, void *stream)
+{
+    float *ps, *pa, *pb;
+    int rc;
+    if ((rc = find_cube(ctx, sum, &ps)) || (rc = find_cube(ctx, a, &pa)) || (rc = find_cube(ctx, b, &pb))) return rc;
+    if ((rc = owned_range(ctx, z_lo, z_hi, "mul_acc"))) return rc;
+    if (order != FDTDX_ORDER_CHAIN && order != FDTDX_ORDER_GOLDEN) return fail(FDTDX_ERR_INVALID, "unknown order %u", order);
+    const uint64_t X = ctx->cfg.X, Y = ctx->cfg.Y;
+    if (radius < 1 || 2 * (uint64_t)radius >= Y || 2 * (uint64_t)radius >= X) return fail(FDTDX_ERR_INVALID, "radius %u leaves no interior", radius);
+    if (Y - 2 * radius > 65535) return fail(FDTDX_ERR_UNSUPPORTED, "more than 65535 interior rows");
+    const fdtdx_geometry &g = ctx->g;
+    const int nq = (int)((X + 3) / 4);
+    for (uint64_t z = z_lo; z < z_hi; z += 65535) {  // planes go to the grid's z dimension
+        const uint64_t n = std::min<uint64_t>(65535, z_hi - z);
+        hipLaunchKernelGGL(mul_acc_kernel, dim3((unsigned)((nq + 127) / 128), (unsigned)(Y - 2 * radius), (unsigned)n), dim3(128), 0,
+                           (hipStream_t)stream, ps, pa, pb, (long long)g.plane, (int)g.pitch_x, (int)X, (int)radius, (long long)z,
+                           order == FDTDX_ORDER_GOLDEN ? 1 : 0);
+        HIP_TRY(hipGetLastError());
     }
     return FDTDX_OK;
 }

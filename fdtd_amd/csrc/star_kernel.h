@@ -73,6 +73,7 @@ struct Lane {
     int hloff[NHK];       // where they go in the LDS image (quad index), -1: none
     int lown[RY];         // own quad in the LDS image
     bool m0, m1, m2, m3;  // which cells of the own quad are interior in x
+    int yrow[RY], x0;     // global y of row j and x of the quad's first cell (composite update only)
 };
 
 // One plane of the march.  The queue holds planes z-M .. z+M+PF; logical slot k (plane z-M+k)
@@ -83,7 +84,8 @@ template <int M, int TQ, int LY, int RY, int ORDER, int PF, int PH>
 __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], float4 (&eo)[RY],
                                            float4 (&hv)[star_nhk(M, TQ, LY, RY)], const Lane<RY, star_nhk(M, TQ, LY, RY)> &L,
                                            float4 *buf, const float *&pn, const float *&pc, float *&po, bool more_n, bool more_c,
-                                           unsigned plane_bytes, const float (&c)[7])
+                                           unsigned plane_bytes, const float (&c)[7], float4 (&vq)[RY], const float *&pv, int gz,
+                                           const double (&kd)[8])
 {
     constexpr int HQ = (M + 3) / 4;
     constexpr int LPQ = TQ + 2 * HQ;
@@ -105,11 +107,19 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
     const __amdgpu_buffer_rsrc_t rc = make_rsrc(pc + pf, nbc);   // halo of plane z+1
     const __amdgpu_buffer_rsrc_t ron = make_rsrc(po + pf, nbc);  // shell components of output plane z+1
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(po, plane_bytes);
-    float4 eo_cur[RY];
+    float4 eo_cur[RY], vq_cur[RY];
 #pragma unroll
     for (int j = 0; j < RY; j++) {
         eo_cur[j] = eo[j];
         q[j][QS(QT - 1)] = buf_ld4(rn, L.goff[j]);
+    }
+    if constexpr (is_composite(ORDER)) {  // the second input of plane z+1, for the cells this thread computes
+        const __amdgpu_buffer_rsrc_t rv = make_rsrc(pv + pf, nbc);
+#pragma unroll
+        for (int j = 0; j < RY; j++) {
+            vq_cur[j] = vq[j];
+            vq[j] = buf_ld4(rv, L.soff[j]);
+        }
     }
 #pragma unroll
     for (int k = 0; k < NHK; k++) hv[k] = buf_ld4(rc, L.hgoff[k]);
@@ -143,7 +153,49 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
         }
         constexpr int XB = 4 * HQ;  // index of the own quad's first cell in xs
         float acc[4];
-        if constexpr (ORDER == ORD_STAR_CHAIN || ORDER == ORD_STAR_GOLDEN) {
+        if constexpr (is_composite(ORDER)) {
+            // main.cu:104-118 / :55-72: cz*z + cy*y + cx*x + vel*scal*(C + wx*SUM(X+r + X-r) + wy*SUM(Y..) + wz*SUM(Z..)) - old
+            float yps[M][4], zps[M][4];  // (+r) + (-r) pairs in float, as both the host and the device form them
+#pragma unroll
+            for (int r = 1; r <= M; r++) {
+                const float4 yp = row[r * LPQ], ym = row[-r * LPQ];
+                const float4 zp = q[j][QS(M + r)], zm = q[j][QS(M - r)];
+                yps[r - 1][0] = yp.x + ym.x, yps[r - 1][1] = yp.y + ym.y, yps[r - 1][2] = yp.z + ym.z, yps[r - 1][3] = yp.w + ym.w;
+                zps[r - 1][0] = zp.x + zm.x, zps[r - 1][1] = zp.y + zm.y, zps[r - 1][2] = zp.z + zm.z, zps[r - 1][3] = zp.w + zm.w;
+            }
+            const float velv[4] = {vq_cur[j].x, vq_cur[j].y, vq_cur[j].z, vq_cur[j].w};
+            const float oldv[4] = {eo_cur[j].x, eo_cur[j].y, eo_cur[j].z, eo_cur[j].w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if constexpr (ORDER == ORD_COMP_GOLDEN) {
+                    double s = (double)xs[XB + i];
+#pragma unroll
+                    for (int r = 1; r <= M; r++) s = s + kd[5] * (double)(xs[XB + i + r] + xs[XB + i - r]);
+#pragma unroll
+                    for (int r = 1; r <= M; r++) s = s + kd[6] * (double)yps[r - 1][i];
+#pragma unroll
+                    for (int r = 1; r <= M; r++) s = s + kd[7] * (double)zps[r - 1][i];
+                    double t = kd[0] * (double)gz + kd[1] * (double)L.yrow[j];
+                    t = t + kd[2] * (double)(L.x0 + i);
+                    t = t + (double)velv[i] * kd[3] / kd[4] * s;
+                    acc[i] = (float)(t - (double)oldv[i]);
+                } else {
+                    const float wxf = (float)kd[5], wyf = (float)kd[6], wzf = (float)kd[7];
+                    float s = xs[XB + i];
+#pragma unroll
+                    for (int r = 1; r <= M; r++) s = __builtin_fmaf(wxf, xs[XB + i + r] + xs[XB + i - r], s);
+#pragma unroll
+                    for (int r = 1; r <= M; r++) s = __builtin_fmaf(wyf, yps[r - 1][i], s);
+#pragma unroll
+                    for (int r = 1; r <= M; r++) s = __builtin_fmaf(wzf, zps[r - 1][i], s);
+                    float t = (float)kd[0] * (float)(unsigned)gz;
+                    t = __builtin_fmaf((float)kd[1], (float)(unsigned)L.yrow[j], t);
+                    t = __builtin_fmaf((float)kd[2], (float)(unsigned)(L.x0 + i), t);
+                    t = __builtin_fmaf(velv[i] * (float)(kd[3] / kd[4]), s, t);
+                    acc[i] = t - oldv[i];
+                }
+            }
+        } else if constexpr (ORDER == ORD_STAR_CHAIN || ORDER == ORD_STAR_GOLDEN) {
             // two cells per instruction (v_pk_mul/add/fma_f32): cells 0,1 and 2,3 of the quad
 #define XP(i) f32x2{xs[(i)], xs[(i) + 1]}
             f32x2 a01 = c0 * XP(XB), a23 = c0 * XP(XB + 2);
@@ -189,13 +241,14 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
     pn += pf;
     pc += pf;
     po += pf;
+    if constexpr (is_composite(ORDER)) pv += pf;
 #undef QS
 }
 
 template <int M, int TQ, int LY, int RY, int ORDER, int PF>
 __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
 {
-    static_assert(ORDER == ORD_STAR_CHAIN || ORDER == ORD_STAR_GOLDEN || M == 1, "jacobi is radius 1");
+    static_assert(ORDER == ORD_STAR_CHAIN || ORDER == ORD_STAR_GOLDEN || is_composite(ORDER) || M == 1, "jacobi is radius 1");
     constexpr int HQ = (M + 3) / 4;           // halo quads on each side in x
     constexpr int NT = TQ * LY;               // threads
     constexpr int CY = LY * RY;               // computed rows per tile
@@ -228,6 +281,7 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
     L.m1 = (x0 + 1 >= p.h) && (x0 + 1 < p.nx - p.h);
     L.m2 = (x0 + 2 >= p.h) && (x0 + 2 < p.nx - p.h);
     L.m3 = (x0 + 3 >= p.h) && (x0 + 3 < p.nx - p.h);
+    L.x0 = x0;
     const bool mall = L.m0 && L.m1 && L.m2 && L.m3;
     const bool many = L.m0 || L.m1 || L.m2 || L.m3;
 #pragma unroll
@@ -238,8 +292,10 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
         const bool cok = qok && (y < p.ny - p.h) && many;
         L.goff[j] = rok ? off : OOB;
         L.soff[j] = cok ? off : OOB;
-        L.eoff[j] = (cok && !mall) ? off : OOB;
+        // the composite update reads the old output of every cell it computes, not only the shell components
+        L.eoff[j] = (cok && (!mall || is_composite(ORDER))) ? off : OOB;
         L.lown[j] = (M + ty + j * LY) * LPQ + HQ + tx;
+        L.yrow[j] = y;
     }
     // ---- halo quads assigned to this thread --------------------------------------------------
 #pragma unroll
@@ -291,6 +347,17 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
     float c[7];
 #pragma unroll
     for (int i = 0; i < 7; i++) c[i] = p.c[i];
+    // composite update: constants, and the second input of the first centre plane
+    double kd[8];
+    float4 vq[RY];
+    const float *pv = nullptr;
+    if constexpr (is_composite(ORDER)) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) kd[i] = p.kd[i];
+        pv = p.vel + (long long)zs * p.plane;
+#pragma unroll
+        for (int j = 0; j < RY; j++) vq[j] = buf_ld4(make_rsrc(pv, plane_bytes), L.soff[j]);
+    }
 
     // one copy of the plane body per queue slot: the queue advances by renaming, never by moves
     int z = zs;
@@ -299,7 +366,7 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
         unroll_phases<0, QT>([&](auto ph) {
             if (z < ze) {
                 plane_step<M, TQ, LY, RY, ORDER, PF, decltype(ph)::value>(q, eo, hv, L, lds[par], pn, pc, po, z < zn_end, z + 1 < ze,
-                                                                        plane_bytes, c);
+                                                                        plane_bytes, c, vq, pv, p.zg0 + z, kd);
                 par ^= 1;
                 z++;
             }

@@ -10,8 +10,11 @@ enum : int {
     ORD_STAR_CHAIN = 0,    // fdtdN.cu device lambda with FMA contraction
     ORD_STAR_GOLDEN = 1,   // fdtdN.cu host golden loop, separate mul/add
     ORD_JACOBI_CHAIN = 2,  // jacobi.cu:31-38 with FMA contraction
-    ORD_JACOBI_GOLDEN = 3  // jacobi.cu:478-485, separate mul/add
+    ORD_JACOBI_GOLDEN = 3, // jacobi.cu:478-485, separate mul/add
+    ORD_COMP_CHAIN = 4,    // main.cu:104-118 device lambda: float constants, FMA contraction
+    ORD_COMP_GOLDEN = 5    // main.cu:55-72 host loop: double constants, evaluated in double, rounded once
 };
+constexpr bool is_composite(int order) { return order == ORD_COMP_CHAIN || order == ORD_COMP_GOLDEN; }
 
 // Everything one sweep launch needs.  Passed by value (kernarg segment).
 struct SweepParams {
@@ -26,6 +29,11 @@ struct SweepParams {
     int zchunk;       // planes marched by one workgroup
     int gx, gy, gz;   // logical grid of tiles: x tiles, y tiles, z chunks (launched as gx*gy*gz blocks in 1-D)
     float c[13];
+    // composite update only (main.cu): second input cube, global z of local plane 0, and the
+    // constants {cz, cy, cx, snum, sden, wx, wy, wz} as doubles
+    const float *vel;
+    int zg0;
+    double kd[8];
 };
 
 // Description of one compiled tile shape.

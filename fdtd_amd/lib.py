@@ -42,6 +42,12 @@ class Program(ctypes.Structure):
                 ("reserved", ctypes.c_uint32), ("coef", ctypes.c_float * 16)]
 
 
+class Composite(ctypes.Structure):
+    """fdtdx_composite: the update of main.cu:102-119 / :55-72."""
+    _fields_ = [("radius", ctypes.c_uint32), ("order", ctypes.c_uint32)] + [(n, ctypes.c_double) for n in
+                ("cz", "cy", "cx", "scal_num", "scal_den", "wx", "wy", "wz")]
+
+
 # every symbol include/fdtdx.h declares, with its signature
 _P = ctypes.POINTER
 _c = ctypes.c_char_p
@@ -73,6 +79,15 @@ SYMBOLS = {
                                                     ctypes.c_uint64, _vp]),
     "fdtdx_propagate2_planes": (ctypes.c_int, [_vp, _c, _c, _c, _P(Program), ctypes.c_uint64, ctypes.c_uint64, _vp]),
     "fdtdx_sweep": (ctypes.c_int, [_vp, _c, _c, _P(Program), ctypes.c_uint32, _vp]),
+    "fdtdx_propagate_composite_planes": (ctypes.c_int, [_vp, _c, _c, _c, _P(Composite), ctypes.c_uint64, ctypes.c_uint64, _vp]),
+    "fdtdx_propagate_composite": (ctypes.c_int, [_vp, _c, _c, _c, _P(Composite), _vp]),
+    "fdtdx_malloc_addr": (ctypes.c_int, [_vp, _c, ctypes.c_uint64]),
+    "fdtdx_transfer_addr_to_gpu": (ctypes.c_int, [_vp, _c, _P(ctypes.c_uint64), ctypes.c_uint64]),
+    "fdtdx_addr_size": (ctypes.c_int, [_vp, _c, _P(ctypes.c_uint64)]),
+    "fdtdx_inject": (ctypes.c_int, [_vp, _c, _c, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _vp]),
+    "fdtdx_filt_planes": (ctypes.c_int, [_vp, _c, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, ctypes.c_uint32,
+                                         ctypes.c_uint64, ctypes.c_uint64, _vp]),
+    "fdtdx_mul_acc": (ctypes.c_int, [_vp, _c, _c, _c, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64, _vp]),
     "fdtdx_halo_region": (ctypes.c_int, [_vp, _c, ctypes.c_int, ctypes.c_int, _P(_vp), _P(ctypes.c_size_t)]),
     "fdtdx_set_option": (ctypes.c_int, [_vp, _c, ctypes.c_int64]),
     "fdtdx_last_launch_info": (ctypes.c_int, [_vp, _c, ctypes.c_size_t]),
@@ -124,6 +139,11 @@ def make_program(kind, radius=1, order=ORDER_CHAIN, coef=None):
     for i, v in enumerate(coef):
         p.coef[i] = float(v)
     return p
+
+
+def make_composite(radius=4, order=ORDER_CHAIN, cz=0.5, cy=-0.2, cx=-0.3, scal_num=1.0, scal_den=6 * 8 + 1, wx=1.0, wy=2.0, wz=3.0):
+    """The constants of main.cu:58-70 / :104-116 by default."""
+    return Composite(radius, order, cz, cy, cx, scal_num, scal_den, wx, wy, wz)
 
 
 def decompose(Z, Y, X, M, rank=0, nprocs=1, pitch_x=0):

@@ -129,6 +129,54 @@ class Stencil:
         _lib.check(self._L.fdtdx_sweep(self._h, a.encode(), b.encode(), ctypes.byref(program), steps,
                                        ctypes.c_void_p(stream or 0)))
 
+    # -- the composite pipeline of main.cu -----------------------------------------------------------
+    def _owned(self):
+        g = self.geometry
+        return int(g.ghost_lo), int(g.ghost_lo) + int(g.owned_planes)
+
+    def propagateComposite(self, output, input, vel, comp, z_lo=None, z_hi=None, stream=None):
+        """main.cu:160 (and :153-154 for a plane range): output = composite(input, vel, output)."""
+        if z_lo is None:
+            _lib.check(self._L.fdtdx_propagate_composite(self._h, output.encode(), input.encode(), vel.encode(),
+                                                         ctypes.byref(comp), ctypes.c_void_p(stream or 0)))
+        else:
+            _lib.check(self._L.fdtdx_propagate_composite_planes(self._h, output.encode(), input.encode(), vel.encode(),
+                                                                ctypes.byref(comp), z_lo, z_hi, ctypes.c_void_p(stream or 0)))
+
+    def mallocAddr(self, name, capacity):
+        """malloc<size_t>(name, n, true), stencil.h:446-466."""
+        _lib.check(self._L.fdtdx_malloc_addr(self._h, name.encode(), capacity))
+
+    def transferAddrToGPU(self, name, global_addr):
+        """transferToGPU(name, addr, n), stencil.h:518-544: linear indices into the undecomposed [Z][Y][X] grid."""
+        a = np.ascontiguousarray(global_addr, np.uint64)
+        _lib.check(self._L.fdtdx_transfer_addr_to_gpu(self._h, name.encode(), a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), len(a)))
+
+    def getAddrSize(self, name):
+        n = ctypes.c_uint64()
+        _lib.check(self._L.fdtdx_addr_size(self._h, name.encode(), ctypes.byref(n)))
+        return n.value
+
+    def inject(self, cube, addr_name, add=1.0, z_lo=None, z_hi=None, stream=None):
+        """inject(n, inject_kernel, cube, addr, add), main.cu:161 (plane range: :155-156)."""
+        lo, hi = self._owned() if z_lo is None else (z_lo, z_hi)
+        _lib.check(self._L.fdtdx_inject(self._h, cube.encode(), addr_name.encode(), add, lo, hi, ctypes.c_void_p(stream or 0)))
+
+    def filt(self, cube, zsel, ysel, xsel, scale=0.9, order=_lib.ORDER_CHAIN, z_lo=None, z_hi=None, stream=None):
+        """filt(filt_kernel, cube), main.cu:162 (plane range: :157-158)."""
+        lo, hi = self._owned() if z_lo is None else (z_lo, z_hi)
+        _lib.check(self._L.fdtdx_filt_planes(self._h, cube.encode(), zsel, ysel, xsel, scale, order, lo, hi,
+                                             ctypes.c_void_p(stream or 0)))
+
+    def mulAcc(self, sum_name, a, b, radius, order=_lib.ORDER_CHAIN, z_lo=None, z_hi=None, stream=None):
+        """filt(mul_kernel, sum, a, b), main.cu:163: sum += a*b on the interior."""
+        g = self.geometry
+        if z_lo is None:
+            z_lo = int(g.ghost_lo) if g.ghost_lo else radius
+            z_hi = int(g.local_planes) - (int(g.ghost_hi) if g.ghost_hi else radius)
+        _lib.check(self._L.fdtdx_mul_acc(self._h, sum_name.encode(), a.encode(), b.encode(), radius, order, z_lo, z_hi,
+                                         ctypes.c_void_p(stream or 0)))
+
     # -- halo regions: stencil.h:639-647 --------------------------------------------------
     def haloRegion(self, name, side, what):
         """(device pointer, float count) of the planes to send (what=0) / receive (what=1)

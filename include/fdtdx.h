@@ -174,6 +174,49 @@ int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const fdtdx_progra
  * so the region is handed to RCCL send/recv (or hipMemcpyPeer) without packing. */
 int fdtdx_halo_region(fdtdx_ctx *ctx, const char *name, int side, int what, float **ptr, size_t *count);
 
+/* ---- the composite pipeline of main.cu (the only caller of inject / filt / address lists) ------------ */
+
+/* The update of main.cu:102-119 (device lambda) / :55-72 (host loop), radius 4 there:
+ *   out = cz*z + cy*y + cx*x + vel*(scal_num/scal_den)*(C + wx*SUM_r(X+r + X-r) + wy*SUM_r(Y+r + Y-r)
+ *                                                         + wz*SUM_r(Z+r + Z-r)) - out
+ * with z, y, x the GLOBAL cell coordinates and C, X.., Y.., Z.. cells of `in`.  FDTDX_ORDER_GOLDEN
+ * evaluates it as the host loop does (double constants, double arithmetic on float pair sums, one
+ * rounding); FDTDX_ORDER_CHAIN as the device lambda (float constants, scal = (float)(num/den), FMAs). */
+typedef struct fdtdx_composite {
+    uint32_t radius, order;
+    double cz, cy, cx, scal_num, scal_den, wx, wy, wz;
+} fdtdx_composite;
+/* propagate(out, in, spill, prop_kernel, getCube("vel"), scal) of main.cu:160 on local planes [z_lo, z_hi)
+ * (main.cu:153-154 are the same launch on boundary planes) / on all planes this rank updates. */
+int fdtdx_propagate_composite_planes(fdtdx_ctx *ctx, const char *out, const char *in, const char *vel,
+                                     const fdtdx_composite *comp, uint64_t z_lo, uint64_t z_hi, void *stream);
+int fdtdx_propagate_composite(fdtdx_ctx *ctx, const char *out, const char *in, const char *vel,
+                              const fdtdx_composite *comp, void *stream);
+
+/* Address lists: malloc<size_t>(name, n, true) (stencil.h:446-466) and transferToGPU(name, addr, n)
+ * (stencil.h:518-544): `global_addr` are linear indices z*Y*X + y*X + x into the undecomposed,
+ * unpadded grid; the addresses whose plane this rank owns are kept and re-based to the local padded
+ * cube.  fdtdx_addr_size = getAddrSize (stencil.h:500-504). */
+int fdtdx_malloc_addr(fdtdx_ctx *ctx, const char *name, uint64_t capacity);
+int fdtdx_transfer_addr_to_gpu(fdtdx_ctx *ctx, const char *name, const uint64_t *global_addr, uint64_t n);
+int fdtdx_addr_size(fdtdx_ctx *ctx, const char *name, uint64_t *count);
+
+/* inject (stencil.h:810-815) with the functor of main.cu:120-123: cube[addr[i]] += add (atomic) for the
+ * listed addresses that lie in local planes [z_lo, z_hi) (the reference keeps separate lists for its
+ * boundary side buffers, main.cu:155-156; here the range selects them). */
+int fdtdx_inject(fdtdx_ctx *ctx, const char *cube, const char *addr_name, float add, uint64_t z_lo, uint64_t z_hi,
+                 void *stream);
+/* filt (stencil.h:817-823, boundary forms :825-841) with the functor of main.cu:124-128: every cell of
+ * local planes [z_lo, z_hi), shell included, whose global z == zsel or y == ysel or x == xsel is
+ * multiplied by `scale` (host order: in double, rounded once; device order: by (float)scale).
+ * A negative selector selects nothing. */
+int fdtdx_filt_planes(fdtdx_ctx *ctx, const char *cube, int64_t zsel, int64_t ysel, int64_t xsel, double scale,
+                      uint32_t order, uint64_t z_lo, uint64_t z_hi, void *stream);
+/* filt with the functor of main.cu:129-133: sum += a*b on the cells at least `radius` away from the
+ * grid faces in y and x, in local planes [z_lo, z_hi) (the caller passes the interior planes). */
+int fdtdx_mul_acc(fdtdx_ctx *ctx, const char *sum, const char *a, const char *b, uint32_t radius, uint32_t order,
+                  uint64_t z_lo, uint64_t z_hi, void *stream);
+
 /* Kernel-selection knobs, for tuning and tests: "zchunks" (z-chunks per sweep launch, 0 = auto),
  * "variant" (tile-shape index, -1 = auto), "temporal" (time steps fdtdx_sweep fuses per launch where
  * a fused kernel exists: 1 = as many as there is a kernel for, 2, 3, or 0 = one launch per step),

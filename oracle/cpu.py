@@ -52,8 +52,15 @@ def lib():
         L.oracle_jacobi7_step.argtypes = [_f32p, _f32p, sz, sz, sz, _f32p, ctypes.c_int, sz, sz]
         L.oracle_run.argtypes = [ctypes.c_int, _f32p, _f32p, sz, sz, sz, ctypes.c_int, _f32p, ctypes.c_int,
                                  ctypes.c_int]
+        _f64p, _u64p = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)
+        L.oracle_composite_sweep.argtypes = [_f32p, _f32p, _f32p, sz, sz, sz, ctypes.c_int, _f64p, ctypes.c_int, sz, sz, sz]
+        L.oracle_inject.argtypes = [_f32p, _u64p, sz, ctypes.c_float]
+        L.oracle_filt.argtypes = [_f32p, sz, sz, sz, sz, sz, sz, sz, ctypes.c_double, ctypes.c_int, sz, sz]
+        L.oracle_mul_acc.argtypes = [_f32p, _f32p, _f32p, sz, sz, sz, ctypes.c_int, ctypes.c_int, sz, sz]
+        L.oracle_main_step.argtypes = [_f32p, _f32p, _f32p, _f32p, _u64p, sz, sz, sz, sz, ctypes.c_int]
         for f in (L.oracle_init_mt, L.oracle_init_jacobi, L.oracle_star_step, L.oracle_spc13_step,
-                  L.oracle_jacobi7_step, L.oracle_run):
+                  L.oracle_jacobi7_step, L.oracle_run, L.oracle_composite_sweep, L.oracle_inject, L.oracle_filt,
+                  L.oracle_mul_acc, L.oracle_main_step):
             f.restype = None
         _lib = L
     return _lib
@@ -99,6 +106,57 @@ def run(kind, a, b, steps, M=1, coef=None, order=ORDER_CHAIN):
     nz, ny, nx = a.shape
     coef = np.ascontiguousarray(default_coef(kind) if coef is None else coef, np.float32)
     lib().oracle_run(KINDS[kind], _p(a), _p(b), nz, ny, nx, M, _p(coef), order, steps)
+
+
+# main.cu composite pipeline ---------------------------------------------------------------------
+MAIN_COEF = np.array([0.5, -0.2, -0.3, 1.0, 6 * 8 + 1, 1.0, 2.0, 3.0], dtype=np.float64)  # main.cu:58-70
+
+
+def _u64(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+
+
+def composite_sweep(out, inp, vel, M=4, coef=None, order=ORDER_CHAIN, z_lo=None, z_hi=None, zg0=0):
+    """main.cu:55-72 (golden) / :104-118 (device order) on local planes [z_lo, z_hi)."""
+    nz, ny, nx = inp.shape
+    k = np.ascontiguousarray(MAIN_COEF if coef is None else coef, np.float64)
+    z_lo = M if z_lo is None else z_lo
+    z_hi = nz - M if z_hi is None else z_hi
+    lib().oracle_composite_sweep(_p(out), _p(inp), _p(vel), nz, ny, nx, M, k.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                 order, z_lo, z_hi, zg0)
+
+
+def inject(cube, addr, add=1.0):
+    """main.cu:73: cube.flat[addr[i]] += add for every i (repeats add repeatedly)."""
+    lib().oracle_inject(_p(cube), _u64(addr), len(addr), add)
+
+
+def filt(cube, zsel, ysel, xsel, scale=0.9, order=ORDER_CHAIN, z_lo=None, z_hi=None, zg0=0):
+    """main.cu:75-79 / :124-128 on local planes [z_lo, z_hi) (default all)."""
+    nz, ny, nx = cube.shape
+    lib().oracle_filt(_p(cube), nz, ny, nx, zg0, zsel, ysel, xsel, scale, order, 0 if z_lo is None else z_lo,
+                      nz if z_hi is None else z_hi)
+
+
+def mul_acc(s, a, b, M=4, order=ORDER_CHAIN, z_lo=None, z_hi=None):
+    """main.cu:81-84 / :129-133."""
+    nz, ny, nx = s.shape
+    lib().oracle_mul_acc(_p(s), _p(a), _p(b), nz, ny, nx, M, order, M if z_lo is None else z_lo,
+                         nz - M if z_hi is None else z_hi)
+
+
+def main_step(p0, p1, vel, s, addr, order=ORDER_CHAIN):
+    """One whole step of main.cu:54-84 (without the swap)."""
+    nz, ny, nx = p0.shape
+    lib().oracle_main_step(_p(p0), _p(p1), _p(vel), _p(s), _u64(addr), len(addr), nz, ny, nx, order)
+
+
+def ref_main_step(p0, p1, vel, s, addr):
+    """The reference's own loop body main.cu:54-84, compiled (oracle/_ref)."""
+    nz, ny, nx = p0.shape
+    a = np.ascontiguousarray(addr, np.uint64)
+    ref().ref_main_step(_p(p0), _p(p1), _p(vel), _p(s), a.ctypes.data_as(ctypes.POINTER(ctypes.c_size_t)), len(a), nz, ny, nx)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -247,3 +247,106 @@ void oracle_run(int kind, float *a, float *b, size_t nz, size_t ny, size_t nx, i
         in = t2;
     }
 }
+
+/* ------------------------------------------------------------------------- */
+/* main.cu composite step: weighted symmetric star with a coordinate term and  */
+/* "- old output", then scatter-add, plane scaling and product-accumulate.      */
+/* k = {cz, cy, cx, snum, sden, wx, wy, wz} as doubles:                          */
+/*   out = cz*z + cy*y + cx*x + vel*snum/sden*(C + wx*SUM_r(X+r + X-r)           */
+/*                                + wy*SUM_r(Y..) + wz*SUM_r(Z..)) - out         */
+/*   ORDER_GOLDEN  the host loop (main.cu:55-72): the constants are double       */
+/*                 literals, so the whole right-hand side is evaluated in double */
+/*                 (pairs are added in float first) and rounded once             */
+/*   ORDER_CHAIN   the device lambda (main.cu:104-118): float constants, float   */
+/*                 arithmetic, every "+ c*v" an FMA; scal = (float)(snum/sden)   */
+/*                 as the call site passes it (main.cu:160)                      */
+/* z, y, x are GLOBAL coordinates: zg0 = global z of local plane 0.              */
+/* ------------------------------------------------------------------------- */
+void oracle_composite_sweep(float *out, const float *in, const float *vel, size_t nzl, size_t ny, size_t nx,
+                            int M, const double *k, int order, size_t z_lo, size_t z_hi, size_t zg0)
+{
+    (void)nzl;
+    const double cz = k[0], cy = k[1], cx = k[2], snum = k[3], sden = k[4], wx = k[5], wy = k[6], wz = k[7];
+    const float czf = (float)cz, cyf = (float)cy, cxf = (float)cx, scal = (float)(snum / sden);
+    const float wxf = (float)wx, wyf = (float)wy, wzf = (float)wz;
+    const ptrdiff_t sy = (ptrdiff_t)nx, sz = (ptrdiff_t)(ny * nx);
+#pragma omp parallel for
+    for (size_t z = z_lo; z < z_hi; z++)
+        for (size_t y = (size_t)M; y < ny - (size_t)M; y++)
+            for (size_t x = (size_t)M; x < nx - (size_t)M; x++) {
+                const size_t a = IDX(z, y, x, ny, nx);
+                const float *p = in + a;
+                const size_t gz = zg0 + z;
+                if (order == ORDER_GOLDEN) {
+                    double s = (double)p[0];
+                    for (int r = 1; r <= M; r++) s = s + wx * (double)(p[r] + p[-r]);
+                    for (int r = 1; r <= M; r++) s = s + wy * (double)(p[r * sy] + p[-r * sy]);
+                    for (int r = 1; r <= M; r++) s = s + wz * (double)(p[r * sz] + p[-r * sz]);
+                    double t = cz * (double)gz + cy * (double)y;
+                    t = t + cx * (double)x;
+                    t = t + (double)vel[a] * snum / sden * s;
+                    out[a] = (float)(t - (double)out[a]);
+                } else {
+                    float s = p[0];
+                    for (int r = 1; r <= M; r++) s = fmaf(wxf, p[r] + p[-r], s);
+                    for (int r = 1; r <= M; r++) s = fmaf(wyf, p[r * sy] + p[-r * sy], s);
+                    for (int r = 1; r <= M; r++) s = fmaf(wzf, p[r * sz] + p[-r * sz], s);
+                    float t = czf * (float)(uint32_t)gz;
+                    t = fmaf(cyf, (float)(uint32_t)y, t);
+                    t = fmaf(cxf, (float)(uint32_t)x, t);
+                    t = fmaf(vel[a] * scal, s, t);
+                    out[a] = t - out[a];
+                }
+            }
+}
+
+/* inject (stencil.h:810-815, main.cu:73 / :120-123): cube[addr[i]] += add, addresses are linear */
+/* indices into the local unpadded array; repeated addresses add repeatedly.                      */
+void oracle_inject(float *cube, const uint64_t *addr, size_t na, float add)
+{
+    for (size_t i = 0; i < na; i++) cube[addr[i]] += add;
+}
+
+/* filt with the functor of main.cu:124-128 (host: :75-79): scale every cell, shell included,   */
+/* whose global z == zsel or y == ysel or x == xsel.  Host order multiplies by the double        */
+/* literal and rounds; device order multiplies by the float constant.                            */
+void oracle_filt(float *cube, size_t nzl, size_t ny, size_t nx, size_t zg0, size_t zsel, size_t ysel, size_t xsel,
+                 double scale, int order, size_t z_lo, size_t z_hi)
+{
+    (void)nzl;
+    const float sf = (float)scale;
+#pragma omp parallel for
+    for (size_t z = z_lo; z < z_hi; z++)
+        for (size_t y = 0; y < ny; y++)
+            for (size_t x = 0; x < nx; x++)
+                if (zg0 + z == zsel || y == ysel || x == xsel) {
+                    float *c = cube + IDX(z, y, x, ny, nx);
+                    *c = (order == ORDER_GOLDEN) ? (float)((double)*c * scale) : *c * sf;
+                }
+}
+
+/* mul (main.cu:81-84 / :129-133): sum += a*b on the interior; the device contracts to an FMA. */
+void oracle_mul_acc(float *sum, const float *a, const float *b, size_t nzl, size_t ny, size_t nx, int M, int order,
+                    size_t z_lo, size_t z_hi)
+{
+    (void)nzl;
+#pragma omp parallel for
+    for (size_t z = z_lo; z < z_hi; z++)
+        for (size_t y = (size_t)M; y < ny - (size_t)M; y++)
+            for (size_t x = (size_t)M; x < nx - (size_t)M; x++) {
+                const size_t i = IDX(z, y, x, ny, nx);
+                sum[i] = (order == ORDER_GOLDEN) ? sum[i] + a[i] * b[i] : fmaf(a[i], b[i], sum[i]);
+            }
+}
+
+/* One step of main.cu:54-84 on an undecomposed grid: p0 = composite(p1, vel, p0); inject +1;    */
+/* scale the planes z = nz/2, y = ny/3, x = nx/4 by 0.9; sum += p0*p1.                            */
+void oracle_main_step(float *p0, const float *p1, const float *vel, float *sum, const uint64_t *addr, size_t na,
+                      size_t nz, size_t ny, size_t nx, int order)
+{
+    const double k[8] = {0.5, -0.2, -0.3, 1.0, 6 * 8 + 1, 1.0, 2.0, 3.0};
+    oracle_composite_sweep(p0, p1, vel, nz, ny, nx, 4, k, order, 4, nz - 4, 0);
+    oracle_inject(p0, addr, na, 1.0f);
+    oracle_filt(p0, nz, ny, nx, 0, nz / 2, ny / 3, nx / 4, 0.9, order, 0, nz);
+    oracle_mul_acc(sum, p0, p1, nz, ny, nx, 4, order, 4, nz - 4);
+}
