@@ -33,14 +33,16 @@ VARIANTS = {  # name -> (program kind, radius, reference driver)
     **{f"fdtd{m}": ("star", m, f"fdtd{m}.cu") for m in range(1, 9)},
     "fdtdspc": ("spc13", 1, "fdtdspc.cu"),
     "jacobi": ("jacobi7", 1, "jacobi.cu"),
+    "main": ("composite", 4, "main.cu"),  # sweep + inject + filt + mul (main.cu:149-171), one rank
 }
+BYTES_PER_UPDATE_MAIN = 28.0  # sweep: p1, vel, old p0 read + p0 write = 16; mul: p0, p1, sum read + sum write counted as 12 (p0 is fresh)
 PEAK_HBM_GBS = 8000.0
 BYTES_PER_UPDATE = 8.0
 
 
 def cpu_baseline(kind, radius, n, budget_s=12.0):
     """Time the CPU golden loop on the host cores; returns the cpu_baseline object."""
-    kid = {"star": 0, "spc13": 1, "jacobi7": 2}[kind]
+    kid = {"star": 0, "spc13": 1, "jacobi7": 2, "composite": 3}[kind]
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     env = dict(os.environ, OMP_NUM_THREADS=str(threads))
@@ -60,6 +62,19 @@ def cpu_baseline(kind, radius, n, budget_s=12.0):
     # fall back to this repo's CPU restatement
     import numpy as np
     from oracle import cpu
+    if kind == "composite":
+        p0, p1, vel = cpu.init_mt(n, n, n, nfields=3)
+        s = np.zeros_like(p0)
+        addr = np.random.default_rng(0).integers(0, n ** 3, 10000).astype(np.uint64)
+        t0 = time.time()
+        steps = 0
+        while time.time() - t0 < budget_s and steps < 2000:
+            cpu.main_step(p0, p1, vel, s, addr, order=cpu.ORDER_GOLDEN)
+            p0, p1 = p1, p0
+            steps += 1
+        dt = time.time() - t0
+        return {"value": round(float(n - 8) ** 3 * steps / dt * 1e-9, 3), "unit": "Gcell/s", "cores": threads, "kind": "port",
+                "sample": f"{steps} steps of the {n}^3 composite loop (oracle/fdtd_oracle.c, gcc -O2 strict IEEE), {dt:.2f} s"}
     if kind == "jacobi7":
         a = cpu.init_jacobi(n, n, n)
         b = a.copy()
@@ -121,8 +136,55 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def time_main(steps, warmup):
+        """The composite pipeline of main.cu on one rank: four launches per step."""
+        import numpy as np
+        from fdtd_amd import Stencil, make_composite
+        n = a.n
+        st = Stencil(n, n, n, 4, device=local_rank)
+        bufs = {}
+        for name in ("p0", "p1", "vel", "sum"):
+            bufs[name] = torch.zeros(int(st.geometry.cube_elems), dtype=torch.float32, device=f"cuda:{local_rank}")
+            st.attachCube(name, bufs[name].data_ptr(), bufs[name].numel() * 4)
+        st.initMt("p0", "p1")
+        st.initMt("vel", "sum")  # any field in [0,1) serves as vel; sum restarts from zero below
+        bufs["sum"].zero_()
+        addr = np.random.default_rng(0).integers(0, n ** 3, 10000).astype(np.uint64)  # main.cu:11,37-41
+        st.mallocAddr("addr", len(addr))
+        st.transferAddrToGPU("addr", addr)
+        comp = make_composite()
+        cs = torch.cuda.current_stream().cuda_stream
+
+        def loop(k):
+            s0, s1 = "p0", "p1"
+            for _ in range(k):
+                st.propagateComposite(s0, s1, "vel", comp, stream=cs)
+                st.inject(s0, "addr", 1.0, stream=cs)
+                st.filt(s0, n // 2, n // 3, n // 4, 0.9, stream=cs)
+                st.mulAcc("sum", s0, s1, 4, stream=cs)
+                s0, s1 = s1, s0
+
+        loop(warmup)
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        loop(steps)
+        e1.record()
+        barrier()
+        dt = time.perf_counter() - t0
+        cells = float(n - 8) ** 3
+        info = st.lastLaunchInfo()
+        st.close()
+        return dict(dt=dt, ev_ms=e0.elapsed_time(e1), cells_rank=cells, cells_all=cells, info=info, kind="composite", radius=4,
+                    launches=steps)
+
     def time_variant(name, steps, warmup):
         kind, radius, _ = VARIANTS[name]
+        if kind == "composite":
+            if world != 1:
+                raise SystemExit("--variant main runs on one rank")
+            return time_main(steps, warmup)
         n = a.n
         # ghost depth: the program radius, or 3 for radius-1 programs on several slabs so that the
         # fused three-step kernel can run with one exchange per three steps
@@ -188,7 +250,8 @@ def main():
     nlaunch = r["launches"] or a.steps
     steps_per_launch = a.steps / nlaunch
     launch_s = r["ev_ms"] * 1e-3 / nlaunch
-    achieved = BYTES_PER_UPDATE * r["cells_rank"] * steps_per_launch / launch_s * 1e-9
+    bpu = BYTES_PER_UPDATE_MAIN if r["kind"] == "composite" else BYTES_PER_UPDATE  # main: per step = 4 launches
+    achieved = bpu * r["cells_rank"] * steps_per_launch / launch_s * 1e-9
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
@@ -209,14 +272,14 @@ def main():
                    "kernel": r["info"]},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": BYTES_PER_UPDATE * r["cells_rank"] * steps_per_launch,
+                     "algorithmic_bytes_per_launch": bpu * r["cells_rank"] * steps_per_launch,
                      "launches": nlaunch, "steps_per_launch": round(steps_per_launch, 3),
                      "launch_us": round(launch_s * 1e6, 2)},
     }
     if a.all_variants and world == 1:
         others = {}
         for name in sorted(VARIANTS):
-            if name == a.variant:
+            if name == a.variant or (name == "main" and a.n < 9):
                 continue
             o = time_variant(name, min(a.steps, 200), 5)
             others[name] = round(o["cells_all"] * min(a.steps, 200) / o["dt"] * 1e-9, 1)

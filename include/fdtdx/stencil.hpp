@@ -51,6 +51,13 @@ inline fdtdx_program jacobi7_program(unsigned order = FDTDX_ORDER_CHAIN)
     for (int i = 0; i < 7; i++) p.coef[i] = c[i];
     return p;
 }
+inline fdtdx_composite main_composite(unsigned order = FDTDX_ORDER_CHAIN)
+{  // main.cu:102-119 (device), :55-72 (host); scal = 1.0/(6*8+1) as passed at main.cu:160
+    fdtdx_composite c{};
+    c.radius = 4, c.order = order;
+    c.cz = 0.5, c.cy = -0.2, c.cx = -0.3, c.scal_num = 1.0, c.scal_den = 6 * 8 + 1, c.wx = 1.0, c.wy = 2.0, c.wz = 3.0;
+    return c;
+}
 
 template <typename DataType, size_t ZSize, size_t YSize, size_t XSize, size_t M, bool FDTD = true>
 class Stencil {
@@ -113,6 +120,39 @@ public:
                               unsigned nsteps, uint64_t z_lo, uint64_t z_hi, void *stream = nullptr)
     {
         FDTDX_ASSERT(fdtdx_propagate_fused_planes(ctx_, output.c_str(), input.c_str(), mid.c_str(), &prog, nsteps, z_lo, z_hi, stream));
+    }
+    // ---- main.cu's pipeline: propagate with vel/scal (main.cu:160), address lists (stencil.h:446-466,518-544),
+    //      inject (stencil.h:810-815), filt (stencil.h:817-823); plane ranges default to what this rank owns ----
+    void propagateComposite(const std::string &output, const std::string &input, const std::string &vel, const fdtdx_composite &comp,
+                            void *stream = nullptr)
+    {
+        FDTDX_ASSERT(fdtdx_propagate_composite(ctx_, output.c_str(), input.c_str(), vel.c_str(), &comp, stream));
+    }
+    void mallocAddr(const std::string &name, size_t n) { FDTDX_ASSERT(fdtdx_malloc_addr(ctx_, name.c_str(), n)); }
+    void transferAddrToGPU(const std::string &name, const uint64_t *global_addr, size_t n)
+    {
+        FDTDX_ASSERT(fdtdx_transfer_addr_to_gpu(ctx_, name.c_str(), global_addr, n));
+    }
+    size_t getAddrSize(const std::string &name)
+    {
+        uint64_t n = 0;
+        FDTDX_ASSERT(fdtdx_addr_size(ctx_, name.c_str(), &n));
+        return (size_t)n;
+    }
+    void inject(const std::string &cube, const std::string &addr, float add, void *stream = nullptr)
+    {
+        FDTDX_ASSERT(fdtdx_inject(ctx_, cube.c_str(), addr.c_str(), add, g_.ghost_lo, g_.ghost_lo + g_.owned_planes, stream));
+    }
+    void filt(const std::string &cube, int64_t zsel, int64_t ysel, int64_t xsel, double scale, unsigned order = FDTDX_ORDER_CHAIN,
+              void *stream = nullptr)
+    {
+        FDTDX_ASSERT(fdtdx_filt_planes(ctx_, cube.c_str(), zsel, ysel, xsel, scale, order, g_.ghost_lo, g_.ghost_lo + g_.owned_planes, stream));
+    }
+    void mulAcc(const std::string &sum, const std::string &a, const std::string &b, unsigned radius, unsigned order = FDTDX_ORDER_CHAIN,
+                void *stream = nullptr)
+    {
+        const uint64_t lo = g_.ghost_lo ? g_.ghost_lo : radius, hi = g_.local_planes - (g_.ghost_hi ? g_.ghost_hi : radius);
+        FDTDX_ASSERT(fdtdx_mul_acc(ctx_, sum.c_str(), a.c_str(), b.c_str(), radius, order, lo, hi, stream));
     }
     // the drivers' whole loop on one rank (fdtd1.cu:68-80): `steps` ping-pong steps, step 0 writes a = f(b)
     void sweep(const std::string &a, const std::string &b, const fdtdx_program &prog, unsigned steps, void *stream = nullptr)

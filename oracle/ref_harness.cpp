@@ -115,7 +115,7 @@ int ref_run(int kind, int M, float *a, float *b, size_t nz, size_t ny, size_t nx
 
 #ifdef REF_BENCH_MAIN
 // Stand-alone timing of the golden loop (the CPU baseline of bench.py, kind "reference"):
-//   ref_bench <kind> <M> <nz> <ny> <nx> <steps>   ->  one JSON line on stdout
+//   ref_bench <kind> <M> <nz> <ny> <nx> <steps>   ->  one JSON line on stdout   (kind 3: main.cu pipeline)
 #include <chrono>
 #include <omp.h>
 int main(int argc, char **argv)
@@ -128,16 +128,38 @@ int main(int argc, char **argv)
     size_t nz = strtoull(argv[3], 0, 10), ny = strtoull(argv[4], 0, 10), nx = strtoull(argv[5], 0, 10);
     int steps = atoi(argv[6]);
     float *a = new float[nz * ny * nx], *b = new float[nz * ny * nx];
-    if (kind == 2)
-        ref_init_jacobi(a, b, (int64_t)nz, (int64_t)ny, (int64_t)nx);
-    else
-        ref_init_mt(a, b, nz, ny, nx);
-    ref_run(kind, M, a, b, nz, ny, nx, 1);  // warm-up: page in both arrays
-    auto t0 = std::chrono::steady_clock::now();
-    ref_run(kind, M, a, b, nz, ny, nx, steps);
-    auto t1 = std::chrono::steady_clock::now();
-    double s = std::chrono::duration<double>(t1 - t0).count();
-    size_t h = (kind == 0) ? (size_t)M : 1;
+    double s;
+    if (kind == 3) {
+        // the composite pipeline of main.cu:52-87: 10000 injection addresses (main.cu:11,37-41), step; swap
+        float *vel = new float[nz * ny * nx], *sum = new float[nz * ny * nx];
+        const size_t na = 10000;
+        size_t *addr = new size_t[na];
+        ref_init_mt3(a, b, vel, sum, nz, ny, nx);
+        for (size_t i = 0; i < na; i++) {
+            size_t x = rand() % nx, y = rand() % ny, z = rand() % nz;
+            addr[i] = (z * ny + y) * nx + x;
+        }
+        ref_main_step(a, b, vel, sum, addr, na, nz, ny, nx);  // warm-up
+        auto t0 = std::chrono::steady_clock::now();
+        for (int t = 0; t < steps; t++) {
+            ref_main_step(a, b, vel, sum, addr, na, nz, ny, nx);
+            std::swap(a, b);
+        }
+        auto t1 = std::chrono::steady_clock::now();
+        s = std::chrono::duration<double>(t1 - t0).count();
+        M = 4;
+    } else {
+        if (kind == 2)
+            ref_init_jacobi(a, b, (int64_t)nz, (int64_t)ny, (int64_t)nx);
+        else
+            ref_init_mt(a, b, nz, ny, nx);
+        ref_run(kind, M, a, b, nz, ny, nx, 1);  // warm-up: page in both arrays
+        auto t0 = std::chrono::steady_clock::now();
+        ref_run(kind, M, a, b, nz, ny, nx, steps);
+        auto t1 = std::chrono::steady_clock::now();
+        s = std::chrono::duration<double>(t1 - t0).count();
+    }
+    size_t h = (kind == 0 || kind == 3) ? (size_t)M : 1;
     double cells = double(nz - 2 * h) * double(ny - 2 * h) * double(nx - 2 * h) * steps;
     double chk = 0;
     for (size_t i = 0; i < nz * ny * nx; i += 4097) chk += a[i] + b[i];
