@@ -74,6 +74,30 @@ class HipSlabBackend:
         if z_hi > z_lo:
             self.st.propagateFusedPlanes(out, inp, mid, program, k, z_lo, z_hi, self._stream(side))
 
+    # -- the composite pipeline of main.cu on plane ranges ---------------------------------------------
+    def comp_sweep(self, out, inp, vel, comp, z_lo, z_hi):
+        if z_hi > z_lo:
+            self.st.propagateComposite(out, inp, vel, comp, z_lo, z_hi, torch.cuda.current_stream().cuda_stream)
+
+    def set_addresses(self, global_addr):
+        """The rank keeps the addresses whose plane it owns (stencil.h:518-544)."""
+        if "addr" not in self.__dict__.setdefault("_lists", set()):
+            self.st.mallocAddr("addr", len(global_addr))
+            self._lists.add("addr")
+        self.st.transferAddrToGPU("addr", global_addr)
+
+    def inject(self, cube, add, z_lo, z_hi):
+        if z_hi > z_lo:
+            self.st.inject(cube, "addr", add, z_lo, z_hi, torch.cuda.current_stream().cuda_stream)
+
+    def filt(self, cube, sel, scale, order, z_lo, z_hi):
+        if z_hi > z_lo:
+            self.st.filt(cube, sel[0], sel[1], sel[2], scale, order, z_lo, z_hi, torch.cuda.current_stream().cuda_stream)
+
+    def mul_acc(self, s, a, b, radius, order, z_lo, z_hi):
+        if z_hi > z_lo:
+            self.st.mulAcc(s, a, b, radius, order, z_lo, z_hi, torch.cuda.current_stream().cuda_stream)
+
     def can_fuse(self, program):
         """Deepest fusion the library has a kernel for (0: none)."""
         ok = (program.order == _lib.ORDER_CHAIN and program.kind in (_lib.STAR, _lib.JACOBI7)
@@ -234,6 +258,55 @@ class SlabRunner:
             else:
                 self.step(b, a)
         return (a, b) if steps % 2 == 1 else (b, a)  # (newest, previous)
+
+
+class CompositeRunner:
+    """The time loop of main.cu:149-171 for one rank: per step
+        s0 = composite(s1, vel, s0); inject(s0); filt(s0); sum += s0*s1; exchange s0; swap
+    with the reference's choreography (boundary side buffers first, main.cu:151-158, then the whole
+    slab, :160-163, then the exchange of both fields, :164-168) replaced by: all operations on the
+    ghost-depth planes next to each neighbour, start their exchange, all operations on the remaining
+    planes beside it.  Only the field just written is exchanged: the other one received its ghost
+    planes when it was written a step earlier."""
+
+    def __init__(self, backend, M, comp, select, scale, rank, nprocs, group=None, exchange="device"):
+        self.b, self.M, self.comp = backend, M, comp
+        self.select, self.scale = select, scale  # filt: (zsel, ysel, xsel) in global coordinates, factor
+        self.x = SlabRunner(backend, M, _lib.make_program("star", radius=comp.radius), rank, nprocs, group, exchange)
+
+    def step(self, s0, s1, vel, total):
+        b, M, x = self.b, self.M, self.x
+        g = b.g
+        lo, hi = x.z_lo, x.z_hi                                    # planes the update writes
+        olo, ohi = int(g.ghost_lo), int(g.ghost_lo) + int(g.owned_planes)  # planes inject/filt touch
+        cuts = []
+        if x.has_lo:
+            cuts.append((olo, min(olo + M, ohi)))
+        if x.has_hi:
+            cuts.append((max(ohi - M, cuts[-1][1] if cuts else olo), ohi))
+        rest_lo = cuts[0][1] if x.has_lo else olo
+        rest_hi = cuts[-1][0] if x.has_hi else ohi
+        order = self.comp.order
+
+        def all_ops(z0, z1):
+            b.comp_sweep(s0, s1, vel, self.comp, max(z0, lo), min(z1, hi))
+            b.inject(s0, 1.0, z0, z1)
+            b.filt(s0, self.select, self.scale, order, z0, z1)
+
+        for z0, z1 in cuts:
+            all_ops(z0, z1)
+        reqs = x._start_exchange(s0)
+        all_ops(rest_lo, rest_hi)
+        b.mul_acc(total, s0, s1, self.comp.radius, order, lo, hi)
+        for r in reqs:
+            r.wait()
+
+    def run(self, p0, p1, vel, total, steps):
+        s0, s1 = p0, p1
+        for _ in range(steps):
+            self.step(s0, s1, vel, total)
+            s0, s1 = s1, s0
+        return s0, s1  # as main.cu leaves them after its swaps
 
 
 def gather_cube(backend, name, Z, Y, X, rank, nprocs, group=None):

@@ -74,6 +74,49 @@ class OracleSlabBackend:
     def can_fuse(self, program):
         return self.fuse
 
+    # -- composite pipeline (main.cu) on plane ranges, by the oracle -----------------------------------
+    def _get(self, name):
+        return np.ascontiguousarray(self.view3(name)[:, :, :self.X])
+
+    def _put(self, name, arr, z_lo, z_hi):
+        self.view3(name)[z_lo:z_hi, :, :self.X] = arr[z_lo:z_hi]
+
+    def comp_sweep(self, out, inp, vel, comp, z_lo, z_hi):
+        if z_hi <= z_lo:
+            return
+        dst = self._get(out)
+        k = np.array([comp.cz, comp.cy, comp.cx, comp.scal_num, comp.scal_den, comp.wx, comp.wy, comp.wz])
+        self.cpu.composite_sweep(dst, self._get(inp), self._get(vel), M=comp.radius, coef=k, order=1 - comp.order,
+                                 z_lo=z_lo, z_hi=z_hi, zg0=int(self.g.first_global))
+        self._put(out, dst, z_lo, z_hi)
+
+    def set_addresses(self, global_addr):
+        g = self.g
+        z = global_addr // (self.Y * self.X)
+        keep = (z >= int(g.owned_begin)) & (z < int(g.owned_begin) + int(g.owned_planes))
+        a = global_addr[keep]
+        self.addr = (a - np.uint64(int(g.first_global) * self.Y * self.X)).astype(np.uint64)  # local, unpadded
+
+    def inject(self, cube, add, z_lo, z_hi):
+        dst = self._get(cube)
+        z = self.addr // np.uint64(self.Y * self.X)
+        self.cpu.inject(dst, np.ascontiguousarray(self.addr[(z >= z_lo) & (z < z_hi)]), add)
+        self._put(cube, dst, z_lo, z_hi)
+
+    def filt(self, cube, sel, scale, order, z_lo, z_hi):
+        if z_hi <= z_lo:
+            return
+        dst = self._get(cube)
+        self.cpu.filt(dst, sel[0], sel[1], sel[2], scale, order=1 - order, z_lo=z_lo, z_hi=z_hi, zg0=int(self.g.first_global))
+        self._put(cube, dst, z_lo, z_hi)
+
+    def mul_acc(self, s, a, b, radius, order, z_lo, z_hi):
+        if z_hi <= z_lo:
+            return
+        dst = self._get(s)
+        self.cpu.mul_acc(dst, self._get(a), self._get(b), M=radius, order=1 - order, z_lo=z_lo, z_hi=z_hi)
+        self._put(s, dst, z_lo, z_hi)
+
     def copy_cube(self, dst, src):
         self.bufs[dst].copy_(self.bufs[src])
 
@@ -106,6 +149,62 @@ def _worker(rank, world, port, kind, M, shape, steps, q, ghost=None):
     q.put((rank, int(g.owned_begin), be.view3("p0")[o0:o1, :, :X].copy(), be.view3("p1")[o0:o1, :, :X].copy()))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _composite_worker(rank, world, port, shape, steps, order, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import cpu
+    from fdtd_amd.slab import CompositeRunner
+    Z, Y, X = shape
+    M = 4
+    p0, p1, vel = cpu.init_mt(Z, Y, X, nfields=3)
+    addr = np.random.default_rng(11).integers(0, Z * Y * X, 400).astype(np.uint64)
+    be = OracleSlabBackend(cpu, Z, Y, X, M, rank, world)
+    g = be.g
+    lo, n = int(g.first_global), int(g.local_planes)
+    for name, arr in (("p0", p0), ("p1", p1), ("vel", vel)):
+        be.alloc(name)
+        be.upload_local(name, arr[lo:lo + n])
+    be.alloc("sum")
+    be.set_addresses(addr)
+    run = CompositeRunner(be, M, lib.make_composite(order=order), (Z // 2, Y // 3, X // 4), 0.9, rank, world)
+    s0, s1 = run.run("p0", "p1", "vel", "sum", steps)
+    o0, o1 = int(g.ghost_lo), int(g.ghost_lo) + int(g.owned_planes)
+    q.put((rank, int(g.owned_begin), [be.view3(nm)[o0:o1, :, :X].copy() for nm in (s0, s1, "sum")]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape,steps", [(2, (26, 11, 13), 4), (3, (40, 10, 12), 3)])
+def test_composite_pipeline_decomposition_invariance(oracle_cpu, world, shape, steps):
+    """main.cu's pipeline on z-slabs (fdtd_amd/slab.py:CompositeRunner, address lists split by owner,
+    filt planes in global coordinates) equals the undecomposed pipeline bit for bit."""
+    order = lib.ORDER_GOLDEN
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_composite_worker, args=(r, world, port, shape, steps, order, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    parts = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    Z, Y, X = shape
+    got = [np.zeros(shape, np.float32) for _ in range(3)]
+    for rank, begin, fields in parts:
+        for gfield, f in zip(got, fields):
+            gfield[begin:begin + f.shape[0]] = f
+    p0, p1, vel = oracle_cpu.init_mt(Z, Y, X, nfields=3)
+    s = np.zeros(shape, np.float32)
+    addr = np.random.default_rng(11).integers(0, Z * Y * X, 400).astype(np.uint64)
+    for _ in range(steps):
+        oracle_cpu.main_step(p0, p1, vel, s, addr, order=oracle_cpu.ORDER_GOLDEN)
+        p0, p1 = p1, p0
+    for gfield, ref in zip(got, (p0, p1, s)):
+        assert np.array_equal(gfield.view(np.uint32), ref.view(np.uint32))
 
 
 def _free_port():
