@@ -31,3 +31,17 @@ def test_cpp_driver_runs():
     out = subprocess.run([EXE, "4", "20"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "GPU time" in out.stdout and "checksum" in out.stdout
+
+
+FUNCTOR_EXE = os.path.join(ROOT, "examples", "functor_driver")
+
+
+@pytest.mark.gpu
+def test_functor_header_lambdas_agree_with_closed_programs():
+    """include/fdtdx/stencil_functor.hpp: device lambdas with the reference's functor signature (star
+    mode, box mode, main.cu's four operations) give what the closed programs give on the same inputs.
+    The binary is built by fdtd_amd/csrc/Makefile (hipcc) and travels with the tree."""
+    assert os.path.exists(FUNCTOR_EXE), "build it with `make -C fdtd_amd/csrc`"
+    out = subprocess.run([FUNCTOR_EXE], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all cases agree" in out.stdout
