@@ -257,7 +257,8 @@ def main():
     if os.path.exists(tf):
         try:
             key = a.variant + ("_singlestep" if a.temporal == 0 and VARIANTS[a.variant][1] == 1 and a.variant != "fdtdspc" else "")
-            traffic = json.load(open(tf)).get(f"{key}_n{a.n}", {}).get("hbm_bytes_per_launch")
+            if world == 1:  # the profiled figure is per whole-slab launch; split launches on several ranks differ
+                traffic = json.load(open(tf)).get(f"{key}_n{a.n}", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
