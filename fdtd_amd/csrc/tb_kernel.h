@@ -126,7 +126,8 @@ __global__ __launch_bounds__(NW * 64) void tb_r1_kernel(const TbParams p)
     // Two fused steps double-buffer the exchange (one barrier per iteration); three would not fit
     // in 160 KB that way, so they share one buffer and close every iteration with a second barrier.
     constexpr int PAR = (KT == 2) ? 2 : 1;
-    __shared__ float4 ex[PAR][KT][NW][2][RX][64];
+    constexpr int NS = (RY == 1) ? 1 : 2;  // a wave of one row publishes it once, for both neighbours
+    __shared__ float4 ex[PAR][KT][NW][NS][RX][64];
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(NW * 64) void tb_r1_kernel(const TbParams p)
 #pragma unroll
             for (int i = 0; i < RX; i++) {
                 ex[par][l][w][0][i][lane] = q[l][l == 0 ? MID : NEW][0][i];
-                ex[par][l][w][1][i][lane] = q[l][l == 0 ? MID : NEW][RY - 1][i];
+                if constexpr (NS == 2) ex[par][l][w][1][i][lane] = q[l][l == 0 ? MID : NEW][RY - 1][i];
             }
         __syncthreads();
         // ---- levels 1..KT: level l at plane pz-l from level l-1 planes pz-l-1, pz-l, pz-l+1 ------
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(NW * 64) void tb_r1_kernel(const TbParams p)
             float4 up[RX], dn[RX], res[RY][RX];
 #pragma unroll
             for (int i = 0; i < RX; i++) {
-                up[i] = ex[par][l - 1][wu][1][i][lane];
+                up[i] = ex[par][l - 1][wu][NS - 1][i][lane];
                 dn[i] = ex[par][l - 1][wd][0][i][lane];
             }
             if (l == 1)
@@ -329,7 +330,7 @@ struct TbRegistrar {
         v.ry = RY;
         v.rx = RX;
         v.threads = NW * 64;
-        v.lds_bytes = (KT == 2 ? 2 : 1) * KT * NW * 2 * RX * 64 * 16;
+        v.lds_bytes = (KT == 2 ? 2 : 1) * KT * NW * (RY == 1 ? 1 : 2) * RX * 64 * 16;
         v.launch = &tb_launch<KT, NW, RY, RX, ORDER>;
         register_tb_variant(v);
     }

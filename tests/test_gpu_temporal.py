@@ -50,11 +50,11 @@ def test_auto_fuses_three_steps(oracle_cpu):
     assert "fused3" in run(oracle_cpu, "star", (13, 61, 509), 10)
 
 
-@pytest.mark.parametrize("variant", range(5))
+@pytest.mark.parametrize("kt,variant", [(2, v) for v in range(9)] + [(3, 0), (3, 1)])
 @pytest.mark.parametrize("kind", ["star", "jacobi7"])
-def test_every_fused_shape(oracle_cpu, kind, variant):
-    info = run(oracle_cpu, kind, (21, 75, 512), 6, tb_variant=variant, tb_zchunks=3, temporal=2)
-    assert "fused2" in info
+def test_every_fused_shape(oracle_cpu, kind, kt, variant):
+    info = run(oracle_cpu, kind, (21, 75, 512), 7, tb_variant=variant, tb_zchunks=3, temporal=kt)
+    assert f"fused{kt}" in info
 
 
 @pytest.mark.parametrize("shape", [(3, 3, 3), (5, 7, 9), (9, 20, 21), (40, 19, 300), (7, 130, 64), (31, 9, 40)])

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--zchunks", default="0")
     ap.add_argument("--out", default="")
     ap.add_argument("--temporal", type=int, default=0, help="1: let sweep() fuse time steps")
+    ap.add_argument("--tb-variant", type=int, default=-1, help="shape index of the fused kernel (-1: default)")
     ap.add_argument("--variants", default="", help="comma list of variant indices (default: all)")
     a = ap.parse_args()
     n = a.n
@@ -37,6 +38,7 @@ def main():
                 st.mallocCube("p1")
                 st.initMt("p0", "p1")
                 st.setOption("temporal", a.temporal)
+                st.setOption("tb_variant", a.tb_variant)
                 prog = make_program(kind, radius=M)
                 cells = float(n - 2 * M) ** 3
                 vlist = [int(x) for x in a.variants.split(',')] if a.variants else None
