@@ -59,7 +59,7 @@ class Stencil:
     # -- pool: stencil.h:553-582, 468-477 -----------------------------------------------
     def mallocCube(self, name, create_halo=False):
         """create_halo is accepted for source compatibility; ghost planes live inside the cube
-        (the side buffers of stencil.h:560-574 are not needed)."""
+        (boundary planes are received straight into them, so the side buffers of stencil.h:560-574 are not needed)."""
         _lib.check(self._L.fdtdx_malloc_cube(self._h, name.encode()))
 
     def attachCube(self, name, device_ptr, nbytes):

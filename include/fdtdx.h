@@ -76,7 +76,7 @@ typedef struct {
     uint32_t flags;       /* reserved, 0 */
 } fdtdx_config;
 
-/* z-slab decomposition and padded layout (stencil.h:398-412; formulas restated in DESIGN.md). */
+/* z-slab decomposition and padded layout (stencil.h:398-412). */
 typedef struct {
     uint64_t pitch_x;       /* PX: floats per row */
     uint64_t plane;         /* Y*PX: floats per plane */

@@ -1,4 +1,4 @@
-"""BASELINE-size checks (512^3) of the HIP sweeps.
+"""Full-size checks (512^3, the grid of the reference drivers, fdtd1.cu:8-10) of the HIP sweeps.
 
   * direct bit-exact comparison with the CPU oracle for a few steps (the oracle finishes a
     512^3 step in well under a second per radius);
@@ -134,7 +134,7 @@ def test_two_slabs_equal_one(kind, M):
 
 @pytest.mark.parametrize("M", [1, 4, 8])
 def test_thousand_step_value_classes(oracle_cpu, M):
-    """BASELINE step count on a reduced grid the oracle can follow: identical zero / denormal /
+    """The drivers' step count (1000, fdtd1.cu:68) on a reduced grid the oracle can follow: identical zero / denormal /
     normal / inf / nan classes everywhere, and identical bits (same arithmetic, same order)."""
     Z, Y, X = 40, 48, 72
     a, b = oracle_cpu.init_mt(Z, Y, X)
