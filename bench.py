@@ -35,7 +35,7 @@ VARIANTS = {  # name -> (program kind, radius, reference driver)
     "jacobi": ("jacobi7", 1, "jacobi.cu"),
     "main": ("composite", 4, "main.cu"),  # sweep + inject + filt + mul (main.cu:149-171), one rank
 }
-BYTES_PER_UPDATE_MAIN = 28.0  # sweep: p1, vel, old p0 read + p0 write = 16; mul: p0, p1, sum read + sum write counted as 12 (p0 is fresh)
+BYTES_PER_UPDATE_MAIN = 24.0  # p1, vel, old p0, sum read + p0, sum write
 PEAK_HBM_GBS = 8000.0
 BYTES_PER_UPDATE = 8.0
 
@@ -158,10 +158,13 @@ def main():
         def loop(k):
             s0, s1 = "p0", "p1"
             for _ in range(k):
-                st.propagateComposite(s0, s1, "vel", comp, stream=cs)
-                st.inject(s0, "addr", 1.0, stream=cs)
-                st.filt(s0, n // 2, n // 3, n // 4, 0.9, stream=cs)
-                st.mulAcc("sum", s0, s1, 4, stream=cs)
+                if a.temporal:  # product-accumulate folded into the update kernel
+                    st.compositeStep(s0, s1, "vel", "sum", "addr", comp, 1.0, n // 2, n // 3, n // 4, 0.9, stream=cs)
+                else:           # the reference's four launches (main.cu:160-163)
+                    st.propagateComposite(s0, s1, "vel", comp, stream=cs)
+                    st.inject(s0, "addr", 1.0, stream=cs)
+                    st.filt(s0, n // 2, n // 3, n // 4, 0.9, stream=cs)
+                    st.mulAcc("sum", s0, s1, 4, stream=cs)
                 s0, s1 = s1, s0
 
         loop(warmup)

@@ -76,6 +76,17 @@ struct Lane {
     int yrow[RY], x0;     // global y of row j and x of the quad's first cell (composite update only)
 };
 
+// State of the composite update (main.cu) carried along the march; unused by the other orders.
+template <int RY>
+struct Comp {
+    float4 vq[RY];    // second input (vel) of the centre plane, prefetched one plane ahead
+    float4 sq[RY];    // running sum of the fused product-accumulate, likewise
+    const float *pv;  // vel, centre plane
+    float *ps;        // sum, centre plane (nullptr: no fused product-accumulate)
+    double kd[8];
+    int zsel, ysel, xsel;  // cells on these planes are scaled later (filt): their product is added then, not here
+};
+
 // One plane of the march.  The queue holds planes z-M .. z+M+PF; logical slot k (plane z-M+k)
 // lives in physical slot (k + PH) % QT, so advancing z by one is a renaming.  Slots 2M+1 ..
 // 2M+PF-1 are loads still in flight; the load issued here (plane z+M+PF) takes the slot that
@@ -84,8 +95,7 @@ template <int M, int TQ, int LY, int RY, int ORDER, int PF, int PH>
 __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], float4 (&eo)[RY],
                                            float4 (&hv)[star_nhk(M, TQ, LY, RY)], const Lane<RY, star_nhk(M, TQ, LY, RY)> &L,
                                            float4 *buf, const float *&pn, const float *&pc, float *&po, bool more_n, bool more_c,
-                                           unsigned plane_bytes, const float (&c)[7], float4 (&vq)[RY], const float *&pv, int gz,
-                                           const double (&kd)[8])
+                                           unsigned plane_bytes, const float (&c)[7], Comp<RY> &cs, int gz)
 {
     constexpr int HQ = (M + 3) / 4;
     constexpr int LPQ = TQ + 2 * HQ;
@@ -107,18 +117,22 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
     const __amdgpu_buffer_rsrc_t rc = make_rsrc(pc + pf, nbc);   // halo of plane z+1
     const __amdgpu_buffer_rsrc_t ron = make_rsrc(po + pf, nbc);  // shell components of output plane z+1
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(po, plane_bytes);
-    float4 eo_cur[RY], vq_cur[RY];
+    float4 eo_cur[RY], vq_cur[RY], sq_cur[RY];
+    const bool fuse_mul = is_composite(ORDER) && cs.ps != nullptr;  // uniform
 #pragma unroll
     for (int j = 0; j < RY; j++) {
         eo_cur[j] = eo[j];
         q[j][QS(QT - 1)] = buf_ld4(rn, L.goff[j]);
     }
     if constexpr (is_composite(ORDER)) {  // the second input of plane z+1, for the cells this thread computes
-        const __amdgpu_buffer_rsrc_t rv = make_rsrc(pv + pf, nbc);
+        const __amdgpu_buffer_rsrc_t rv = make_rsrc(cs.pv + pf, nbc);
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(cs.ps + pf, fuse_mul ? nbc : 0u);
 #pragma unroll
         for (int j = 0; j < RY; j++) {
-            vq_cur[j] = vq[j];
-            vq[j] = buf_ld4(rv, L.soff[j]);
+            vq_cur[j] = cs.vq[j];
+            cs.vq[j] = buf_ld4(rv, L.soff[j]);
+            sq_cur[j] = cs.sq[j];
+            cs.sq[j] = buf_ld4(rs, L.soff[j]);
         }
     }
 #pragma unroll
@@ -170,17 +184,17 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
                 if constexpr (ORDER == ORD_COMP_GOLDEN) {
                     double s = (double)xs[XB + i];
 #pragma unroll
-                    for (int r = 1; r <= M; r++) s = s + kd[5] * (double)(xs[XB + i + r] + xs[XB + i - r]);
+                    for (int r = 1; r <= M; r++) s = s + cs.kd[5] * (double)(xs[XB + i + r] + xs[XB + i - r]);
 #pragma unroll
-                    for (int r = 1; r <= M; r++) s = s + kd[6] * (double)yps[r - 1][i];
+                    for (int r = 1; r <= M; r++) s = s + cs.kd[6] * (double)yps[r - 1][i];
 #pragma unroll
-                    for (int r = 1; r <= M; r++) s = s + kd[7] * (double)zps[r - 1][i];
-                    double t = kd[0] * (double)gz + kd[1] * (double)L.yrow[j];
-                    t = t + kd[2] * (double)(L.x0 + i);
-                    t = t + (double)velv[i] * kd[3] / kd[4] * s;
+                    for (int r = 1; r <= M; r++) s = s + cs.kd[7] * (double)zps[r - 1][i];
+                    double t = cs.kd[0] * (double)gz + cs.kd[1] * (double)L.yrow[j];
+                    t = t + cs.kd[2] * (double)(L.x0 + i);
+                    t = t + (double)velv[i] * cs.kd[3] / cs.kd[4] * s;
                     acc[i] = (float)(t - (double)oldv[i]);
                 } else {
-                    const float wxf = (float)kd[5], wyf = (float)kd[6], wzf = (float)kd[7];
+                    const float wxf = (float)cs.kd[5], wyf = (float)cs.kd[6], wzf = (float)cs.kd[7];
                     float s = xs[XB + i];
 #pragma unroll
                     for (int r = 1; r <= M; r++) s = __builtin_fmaf(wxf, xs[XB + i + r] + xs[XB + i - r], s);
@@ -188,12 +202,25 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
                     for (int r = 1; r <= M; r++) s = __builtin_fmaf(wyf, yps[r - 1][i], s);
 #pragma unroll
                     for (int r = 1; r <= M; r++) s = __builtin_fmaf(wzf, zps[r - 1][i], s);
-                    float t = (float)kd[0] * (float)(unsigned)gz;
-                    t = __builtin_fmaf((float)kd[1], (float)(unsigned)L.yrow[j], t);
-                    t = __builtin_fmaf((float)kd[2], (float)(unsigned)(L.x0 + i), t);
-                    t = __builtin_fmaf(velv[i] * (float)(kd[3] / kd[4]), s, t);
+                    float t = (float)cs.kd[0] * (float)(unsigned)gz;
+                    t = __builtin_fmaf((float)cs.kd[1], (float)(unsigned)L.yrow[j], t);
+                    t = __builtin_fmaf((float)cs.kd[2], (float)(unsigned)(L.x0 + i), t);
+                    t = __builtin_fmaf(velv[i] * (float)(cs.kd[3] / cs.kd[4]), s, t);
                     acc[i] = t - oldv[i];
                 }
+            }
+            if (fuse_mul) {
+                // sum += out*in (main.cu:129-133) for the cells no later operation of the step changes: cells on
+                // the planes filt scales get their product there; the few cells inject touches are redone by the host
+                const bool rowsel = (gz == cs.zsel) || (L.yrow[j] == cs.ysel);
+                const bool mi[4] = {L.m0, L.m1, L.m2, L.m3};
+                float sv[4] = {sq_cur[j].x, sq_cur[j].y, sq_cur[j].z, sq_cur[j].w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float prod = (ORDER == ORD_COMP_GOLDEN) ? sv[i] + acc[i] * xs[XB + i] : __builtin_fmaf(acc[i], xs[XB + i], sv[i]);
+                    sv[i] = (mi[i] && !rowsel && (L.x0 + i != cs.xsel)) ? prod : sv[i];
+                }
+                buf_st4(make_rsrc(cs.ps, plane_bytes), L.soff[j], sv[0], sv[1], sv[2], sv[3]);
             }
         } else if constexpr (ORDER == ORD_STAR_CHAIN || ORDER == ORD_STAR_GOLDEN) {
             // two cells per instruction (v_pk_mul/add/fma_f32): cells 0,1 and 2,3 of the quad
@@ -241,7 +268,10 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
     pn += pf;
     pc += pf;
     po += pf;
-    if constexpr (is_composite(ORDER)) pv += pf;
+    if constexpr (is_composite(ORDER)) {
+        cs.pv += pf;
+        if (fuse_mul) cs.ps += pf;
+    }
 #undef QS
 }
 
@@ -347,16 +377,20 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
     float c[7];
 #pragma unroll
     for (int i = 0; i < 7; i++) c[i] = p.c[i];
-    // composite update: constants, and the second input of the first centre plane
-    double kd[8];
-    float4 vq[RY];
-    const float *pv = nullptr;
+    // composite update: constants, and the second input / running sum of the first centre plane
+    Comp<RY> cs;
+    cs.pv = nullptr, cs.ps = nullptr;
     if constexpr (is_composite(ORDER)) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) kd[i] = p.kd[i];
-        pv = p.vel + (long long)zs * p.plane;
+        for (int i = 0; i < 8; i++) cs.kd[i] = p.kd[i];
+        cs.zsel = p.sel[0], cs.ysel = p.sel[1], cs.xsel = p.sel[2];
+        cs.pv = p.vel + (long long)zs * p.plane;
+        cs.ps = p.sum ? p.sum + (long long)zs * p.plane : nullptr;
 #pragma unroll
-        for (int j = 0; j < RY; j++) vq[j] = buf_ld4(make_rsrc(pv, plane_bytes), L.soff[j]);
+        for (int j = 0; j < RY; j++) {
+            cs.vq[j] = buf_ld4(make_rsrc(cs.pv, plane_bytes), L.soff[j]);
+            cs.sq[j] = buf_ld4(make_rsrc(cs.ps, p.sum ? plane_bytes : 0u), L.soff[j]);
+        }
     }
 
     // one copy of the plane body per queue slot: the queue advances by renaming, never by moves
@@ -366,7 +400,7 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
         unroll_phases<0, QT>([&](auto ph) {
             if (z < ze) {
                 plane_step<M, TQ, LY, RY, ORDER, PF, decltype(ph)::value>(q, eo, hv, L, lds[par], pn, pc, po, z < zn_end, z + 1 < ze,
-                                                                        plane_bytes, c, vq, pv, p.zg0 + z, kd);
+                                                                        plane_bytes, c, cs, p.zg0 + z);
                 par ^= 1;
                 z++;
             }

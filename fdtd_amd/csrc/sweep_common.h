@@ -34,6 +34,8 @@ struct SweepParams {
     const float *vel;
     int zg0;
     double kd[8];
+    float *sum;   // fused product-accumulate target (nullptr: none)
+    int sel[3];   // global z, y, x of the planes filt scales afterwards (-1: none)
 };
 
 // Description of one compiled tile shape.

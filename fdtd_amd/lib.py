@@ -81,6 +81,8 @@ SYMBOLS = {
     "fdtdx_sweep": (ctypes.c_int, [_vp, _c, _c, _P(Program), ctypes.c_uint32, _vp]),
     "fdtdx_propagate_composite_planes": (ctypes.c_int, [_vp, _c, _c, _c, _P(Composite), ctypes.c_uint64, ctypes.c_uint64, _vp]),
     "fdtdx_propagate_composite": (ctypes.c_int, [_vp, _c, _c, _c, _P(Composite), _vp]),
+    "fdtdx_composite_step": (ctypes.c_int, [_vp, _c, _c, _c, _c, _c, _P(Composite), ctypes.c_float, ctypes.c_int64, ctypes.c_int64,
+                                            ctypes.c_int64, ctypes.c_double, _vp]),
     "fdtdx_malloc_addr": (ctypes.c_int, [_vp, _c, ctypes.c_uint64]),
     "fdtdx_transfer_addr_to_gpu": (ctypes.c_int, [_vp, _c, _P(ctypes.c_uint64), ctypes.c_uint64]),
     "fdtdx_addr_size": (ctypes.c_int, [_vp, _c, _P(ctypes.c_uint64)]),

@@ -143,6 +143,13 @@ class Stencil:
             _lib.check(self._L.fdtdx_propagate_composite_planes(self._h, output.encode(), input.encode(), vel.encode(),
                                                                 ctypes.byref(comp), z_lo, z_hi, ctypes.c_void_p(stream or 0)))
 
+    def compositeStep(self, output, input, vel, sum_name, addr_name, comp, add, zsel, ysel, xsel, scale, stream=None):
+        """One whole step of main.cu:160-163 (update, inject, filt, mul) with the product-accumulate
+        folded into the update kernel; same results as the four separate calls."""
+        _lib.check(self._L.fdtdx_composite_step(self._h, output.encode(), input.encode(), vel.encode(), sum_name.encode(),
+                                                addr_name.encode(), ctypes.byref(comp), add, zsel, ysel, xsel, scale,
+                                                ctypes.c_void_p(stream or 0)))
+
     def mallocAddr(self, name, capacity):
         """malloc<size_t>(name, n, true), stencil.h:446-466."""
         _lib.check(self._L.fdtdx_malloc_addr(self._h, name.encode(), capacity))

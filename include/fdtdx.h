@@ -217,6 +217,15 @@ int fdtdx_filt_planes(fdtdx_ctx *ctx, const char *cube, int64_t zsel, int64_t ys
 int fdtdx_mul_acc(fdtdx_ctx *ctx, const char *sum, const char *a, const char *b, uint32_t radius, uint32_t order,
                   uint64_t z_lo, uint64_t z_hi, void *stream);
 
+/* One whole step of main.cu:160-163 on the planes this rank owns: out = composite(in, vel, out); inject(out);
+ * filt(out); sum += out*in -- with the product-accumulate folded into the update kernel, so that a step moves
+ * 24 instead of 32 bytes per cell.  The results are exactly those of the four calls above (cells that inject or
+ * filt change after the update get their product from the final value).  Allocates a buffer of one float per
+ * listed address inside the context on first use. */
+int fdtdx_composite_step(fdtdx_ctx *ctx, const char *out, const char *in, const char *vel, const char *sum,
+                         const char *addr_name, const fdtdx_composite *comp, float add, int64_t zsel, int64_t ysel,
+                         int64_t xsel, double scale, void *stream);
+
 /* Kernel-selection knobs, for tuning and tests: "zchunks" (z-chunks per sweep launch, 0 = auto),
  * "variant" (tile-shape index, -1 = auto), "temporal" (time steps fdtdx_sweep fuses per launch where
  * a fused kernel exists: 1 = as many as there is a kernel for, 2, 3, or 0 = one launch per step),

@@ -16,7 +16,7 @@ ORD = {ORDER_CHAIN: 1, ORDER_GOLDEN: 0}
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_main_v1.npz")
 
 
-def gpu_pipeline(shape, p0, p1, vel, s, addr, steps, order, variant=-1, zchunks=0):
+def gpu_pipeline(shape, p0, p1, vel, s, addr, steps, order, variant=-1, zchunks=0, fused=False):
     Z, Y, X = shape
     with Stencil(Z, Y, X, 4) as st:
         for n in ("p0", "p1", "vel", "sum"):
@@ -33,10 +33,13 @@ def gpu_pipeline(shape, p0, p1, vel, s, addr, steps, order, variant=-1, zchunks=
         comp = make_composite(order=order)
         s0, s1 = "p0", "p1"
         for _ in range(steps):
-            st.propagateComposite(s0, s1, "vel", comp)
-            st.inject(s0, "addr", 1.0)
-            st.filt(s0, Z // 2, Y // 3, X // 4, 0.9, order)
-            st.mulAcc("sum", s0, s1, 4, order)
+            if fused:
+                st.compositeStep(s0, s1, "vel", "sum", "addr", comp, 1.0, Z // 2, Y // 3, X // 4, 0.9)
+            else:
+                st.propagateComposite(s0, s1, "vel", comp)
+                st.inject(s0, "addr", 1.0)
+                st.filt(s0, Z // 2, Y // 3, X // 4, 0.9, order)
+                st.mulAcc("sum", s0, s1, 4, order)
             s0, s1 = s1, s0
         st.sync()
         out = [np.empty(shape, np.float32) for _ in range(3)]
@@ -70,15 +73,20 @@ def same(got, ref, info=""):
         assert len(bad) == 0, f"{name}: {len(bad)} cells differ, first {bad[:3].tolist()} {info}"
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("order", [ORDER_CHAIN, ORDER_GOLDEN])
-def test_every_composite_shape(oracle_cpu, order):
+def test_every_composite_shape(oracle_cpu, order, fused):
     shape = (17, 75, 2 * 4 * 64 + 27)
     p0, p1, vel, s, addr = inputs(oracle_cpu, shape, 2000)
+    # injection addresses on the planes filt scales, on the shell and next to it: every case of the fused step
+    Z, Y, X = shape
+    addr[:6] = [(Z // 2) * Y * X + 9 * X + 11, 5 * Y * X + (Y // 3) * X + 40, 6 * Y * X + 20 * X + X // 4, 3, 4 * Y * X + 4 * X + 4,
+                (Z // 2) * Y * X + (Y // 3) * X + X // 4]
     ref = oracle_pipeline(oracle_cpu, p0, p1, vel, s, addr, 3, order)
     v = 0
     while True:
         try:
-            got, info = gpu_pipeline(shape, p0, p1, vel, s, addr, 3, order, variant=v, zchunks=2)
+            got, info = gpu_pipeline(shape, p0, p1, vel, s, addr, 3, order, variant=v, zchunks=2, fused=fused)
         except FdtdxError as e:
             assert e.code == lib.ERR_UNSUPPORTED
             break
@@ -87,11 +95,13 @@ def test_every_composite_shape(oracle_cpu, order):
     assert v >= 3
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("shape", [(9, 9, 9), (12, 11, 40), (23, 40, 130)])
-def test_composite_small_grids(oracle_cpu, shape):
+def test_composite_small_grids(oracle_cpu, shape, fused):
     p0, p1, vel, s, addr = inputs(oracle_cpu, shape, 50)
     for order in (ORDER_CHAIN, ORDER_GOLDEN):
-        same(gpu_pipeline(shape, p0, p1, vel, s, addr, 5, order)[0], oracle_pipeline(oracle_cpu, p0, p1, vel, s, addr, 5, order))
+        same(gpu_pipeline(shape, p0, p1, vel, s, addr, 5, order, fused=fused)[0],
+             oracle_pipeline(oracle_cpu, p0, p1, vel, s, addr, 5, order))
 
 
 def test_host_order_equals_reference_fixture(oracle_cpu):
@@ -102,11 +112,11 @@ def test_host_order_equals_reference_fixture(oracle_cpu):
     same(got, [z["p0"], z["p1"], z["sum"]])
 
 
-@pytest.mark.parametrize("order", [ORDER_CHAIN, ORDER_GOLDEN])
-def test_composite_fullsize(oracle_cpu, order):
+@pytest.mark.parametrize("order,fused", [(ORDER_CHAIN, False), (ORDER_GOLDEN, False), (ORDER_CHAIN, True)])
+def test_composite_fullsize(oracle_cpu, order, fused):
     shape = (512, 512, 512)
     p0, p1, vel, s, addr = inputs(oracle_cpu, shape, 10000)  # main.cu:11
-    same(gpu_pipeline(shape, p0, p1, vel, s, addr, 2, order)[0], oracle_pipeline(oracle_cpu, p0, p1, vel, s, addr, 2, order))
+    same(gpu_pipeline(shape, p0, p1, vel, s, addr, 2, order, fused=fused)[0], oracle_pipeline(oracle_cpu, p0, p1, vel, s, addr, 2, order))
 
 
 def test_two_slabs_equal_one(oracle_cpu):
