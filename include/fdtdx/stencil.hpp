@@ -128,6 +128,14 @@ public:
     {
         FDTDX_ASSERT(fdtdx_propagate_composite(ctx_, output.c_str(), input.c_str(), vel.c_str(), &comp, stream));
     }
+    // the four calls of main.cu:160-163 as one, product-accumulate folded into the update (same results)
+    void compositeStep(const std::string &output, const std::string &input, const std::string &vel, const std::string &sum,
+                       const std::string &addr, const fdtdx_composite &comp, float add, int64_t zsel, int64_t ysel, int64_t xsel, double scale,
+                       void *stream = nullptr)
+    {
+        FDTDX_ASSERT(fdtdx_composite_step(ctx_, output.c_str(), input.c_str(), vel.c_str(), sum.c_str(), addr.c_str(), &comp, add, zsel, ysel,
+                                          xsel, scale, stream));
+    }
     void mallocAddr(const std::string &name, size_t n) { FDTDX_ASSERT(fdtdx_malloc_addr(ctx_, name.c_str(), n)); }
     void transferAddrToGPU(const std::string &name, const uint64_t *global_addr, size_t n)
     {
