@@ -8,6 +8,7 @@
 #include "../../include/fdtdx.h"
 #include "sweep_common.h"
 #include "tb_kernel.h"
+#include "yee_kernel.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -970,6 +971,75 @@ extern "C" int fdtdx_mul_acc(fdtdx_ctx *ctx, const char *sum, const char *a, con
                            order == FDTDX_ORDER_GOLDEN ? 1 : 0);
         HIP_TRY(hipGetLastError());
     }
+    return FDTDX_OK;
+}
+
+// ---- extension: staggered-grid E/H updates (no counterpart in the reference; yee_kernel.h) ------------
+extern "C" int fdtdx_yee3d_half(fdtdx_ctx *ctx, const char *const fields[6], int which, float coef, uint32_t order, uint64_t z_lo,
+                                uint64_t z_hi, void *stream)
+{
+    if (!ctx || !fields) return fail(FDTDX_ERR_INVALID, "null argument");
+    if (which != 0 && which != 1) return fail(FDTDX_ERR_INVALID, "which must be 0 (H half step) or 1 (E half step)");
+    if (order != FDTDX_ORDER_CHAIN && order != FDTDX_ORDER_GOLDEN) return fail(FDTDX_ERR_INVALID, "unknown order %u", order);
+    const fdtdx_geometry &g = ctx->g;
+    if (z_lo < 1 || z_hi > g.local_planes - 1 || z_lo > z_hi) return fail(FDTDX_ERR_INVALID, "plane range [%llu,%llu) needs one plane of support on each side", (unsigned long long)z_lo, (unsigned long long)z_hi);
+    YeeParams p;
+    int rc;
+    for (int i = 0; i < 6; i++) {
+        if ((rc = find_cube(ctx, fields[i], &p.f[i]))) return rc;
+        for (int k = 0; k < i; k++)
+            if (p.f[k] == p.f[i]) return fail(FDTDX_ERR_INVALID, "the six fields must be six different cubes");
+    }
+    if (z_lo == z_hi) return FDTDX_OK;
+    p.plane = (long long)g.plane, p.px = (int)g.pitch_x, p.nx = (int)ctx->cfg.X, p.ny = (int)ctx->cfg.Y;
+    p.z_lo = (int)z_lo, p.z_hi = (int)z_hi, p.coef = coef;
+    const unsigned gx = (unsigned)(((ctx->cfg.X + 3) / 4 + 63) / 64), gy = (unsigned)((ctx->cfg.Y - 2 + 3) / 4);
+    const long long nz = (long long)(z_hi - z_lo);
+    // a few thousand workgroups of 4 waves keep the chip busy; z chunks of at least 16 planes keep the register reuse
+    long long chunks = std::max<long long>(1, std::min<long long>(nz / 16, 4096 / std::max<long long>(1, (long long)gx * gy)));
+    p.zchunk = (int)((nz + chunks - 1) / chunks);
+    const unsigned gz = (unsigned)((nz + p.zchunk - 1) / p.zchunk);
+    if (gy > 65535 || gz > 65535) return fail(FDTDX_ERR_UNSUPPORTED, "grid too large");
+    const dim3 grid(gx, gy, gz), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const bool gold = order == FDTDX_ORDER_GOLDEN;
+    if (which == 0 && !gold) hipLaunchKernelGGL((yee3d_half_kernel<0, 0>), grid, block, 0, s, p);
+    if (which == 0 && gold) hipLaunchKernelGGL((yee3d_half_kernel<0, 1>), grid, block, 0, s, p);
+    if (which == 1 && !gold) hipLaunchKernelGGL((yee3d_half_kernel<1, 0>), grid, block, 0, s, p);
+    if (which == 1 && gold) hipLaunchKernelGGL((yee3d_half_kernel<1, 1>), grid, block, 0, s, p);
+    HIP_TRY(hipGetLastError());
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_yee3d_step(fdtdx_ctx *ctx, const char *const fields[6], float ce, float ch, uint32_t order, void *stream)
+{
+    if (!ctx) return fail(FDTDX_ERR_INVALID, "null context");
+    if (ctx->cfg.nprocs != 1) return fail(FDTDX_ERR_UNSUPPORTED, "fdtdx_yee3d_step runs on one rank; use fdtdx_yee3d_half with an exchange of H after the first half");
+    const uint64_t hi = ctx->g.local_planes - 1;
+    int rc = fdtdx_yee3d_half(ctx, fields, 0, ch, order, 1, hi, stream);
+    if (rc) return rc;
+    return fdtdx_yee3d_half(ctx, fields, 1, ce, order, 1, hi, stream);
+}
+
+extern "C" int fdtdx_yee2d_steps(int device, float *ex, float *ey, float *hz, uint64_t nx, uint64_t ny, int t0, int steps, float ce, float ch,
+                                 uint32_t order, void *stream)
+{
+    if (!ex || !ey || !hz) return fail(FDTDX_ERR_INVALID, "null argument");
+    if (nx < 2 || ny < 2 || nx > 65535 || ny > 0x7fffffffu) return fail(FDTDX_ERR_INVALID, "2-D grid %llux%llu out of range", (unsigned long long)nx, (unsigned long long)ny);
+    if (order != FDTDX_ORDER_CHAIN && order != FDTDX_ORDER_GOLDEN) return fail(FDTDX_ERR_INVALID, "unknown order %u", order);
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    const dim3 grid((unsigned)((ny + 255) / 256), (unsigned)nx), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    for (int t = t0; t < t0 + steps; t++) {
+        if (order == FDTDX_ORDER_GOLDEN) {
+            hipLaunchKernelGGL((yee2d_e_kernel<1>), grid, block, 0, s, ex, ey, (const float *)hz, (int)nx, (int)ny, (float)t, ce);
+            hipLaunchKernelGGL((yee2d_h_kernel<1>), grid, block, 0, s, (const float *)ex, (const float *)ey, hz, (int)nx, (int)ny, ch);
+        } else {
+            hipLaunchKernelGGL((yee2d_e_kernel<0>), grid, block, 0, s, ex, ey, (const float *)hz, (int)nx, (int)ny, (float)t, ce);
+            hipLaunchKernelGGL((yee2d_h_kernel<0>), grid, block, 0, s, (const float *)ex, (const float *)ey, hz, (int)nx, (int)ny, ch);
+        }
+    }
+    HIP_TRY(hipGetLastError());
     return FDTDX_OK;
 }
 

@@ -90,6 +90,10 @@ SYMBOLS = {
     "fdtdx_filt_planes": (ctypes.c_int, [_vp, _c, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, ctypes.c_uint32,
                                          ctypes.c_uint64, ctypes.c_uint64, _vp]),
     "fdtdx_mul_acc": (ctypes.c_int, [_vp, _c, _c, _c, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64, _vp]),
+    "fdtdx_yee3d_half": (ctypes.c_int, [_vp, _P(_c), ctypes.c_int, ctypes.c_float, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64, _vp]),
+    "fdtdx_yee3d_step": (ctypes.c_int, [_vp, _P(_c), ctypes.c_float, ctypes.c_float, ctypes.c_uint32, _vp]),
+    "fdtdx_yee2d_steps": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_float, ctypes.c_float, ctypes.c_uint32, _vp]),
     "fdtdx_halo_region": (ctypes.c_int, [_vp, _c, ctypes.c_int, ctypes.c_int, _P(_vp), _P(ctypes.c_size_t)]),
     "fdtdx_set_option": (ctypes.c_int, [_vp, _c, ctypes.c_int64]),
     "fdtdx_last_launch_info": (ctypes.c_int, [_vp, _c, ctypes.c_size_t]),
@@ -146,6 +150,13 @@ def make_program(kind, radius=1, order=ORDER_CHAIN, coef=None):
 def make_composite(radius=4, order=ORDER_CHAIN, cz=0.5, cy=-0.2, cx=-0.3, scal_num=1.0, scal_den=6 * 8 + 1, wx=1.0, wy=2.0, wz=3.0):
     """The constants of main.cu:58-70 / :104-116 by default."""
     return Composite(radius, order, cz, cy, cx, scal_num, scal_den, wx, wy, wz)
+
+
+def yee2d_steps(ex_ptr, ey_ptr, hz_ptr, nx, ny, t0, steps, ce=0.5, ch=0.7, order=ORDER_CHAIN, device=-1, stream=None):
+    """Extension (no counterpart in the reference): `steps` steps of the 2-D ex/ey/hz scheme on dense
+    [nx][ny] device arrays given by their device pointers."""
+    check(load().fdtdx_yee2d_steps(device, ctypes.c_void_p(ex_ptr), ctypes.c_void_p(ey_ptr), ctypes.c_void_p(hz_ptr), nx, ny, t0, steps,
+                                   ce, ch, order, ctypes.c_void_p(stream or 0)))
 
 
 def decompose(Z, Y, X, M, rank=0, nprocs=1, pitch_x=0):

@@ -184,6 +184,21 @@ class Stencil:
         _lib.check(self._L.fdtdx_mul_acc(self._h, sum_name.encode(), a.encode(), b.encode(), radius, order, z_lo, z_hi,
                                          ctypes.c_void_p(stream or 0)))
 
+    # -- extension: 3-D Yee E/H update (no counterpart in the reference) ---------------------------------
+    @staticmethod
+    def _names(fields):
+        assert len(fields) == 6
+        return (ctypes.c_char_p * 6)(*[f.encode() for f in fields])
+
+    def yee3dHalf(self, fields, which, coef, order=_lib.ORDER_CHAIN, z_lo=None, z_hi=None, stream=None):
+        """fields = (Ex, Ey, Ez, Hx, Hy, Hz) cube names; which 0: H -= coef*curl E, 1: E += coef*curl H."""
+        if z_lo is None:
+            z_lo, z_hi = 1, int(self.geometry.local_planes) - 1
+        _lib.check(self._L.fdtdx_yee3d_half(self._h, self._names(fields), which, coef, order, z_lo, z_hi, ctypes.c_void_p(stream or 0)))
+
+    def yee3dStep(self, fields, ce, ch, order=_lib.ORDER_CHAIN, stream=None):
+        _lib.check(self._L.fdtdx_yee3d_step(self._h, self._names(fields), ce, ch, order, ctypes.c_void_p(stream or 0)))
+
     # -- halo regions: stencil.h:639-647 --------------------------------------------------
     def haloRegion(self, name, side, what):
         """(device pointer, float count) of the planes to send (what=0) / receive (what=1)

@@ -226,6 +226,24 @@ int fdtdx_composite_step(fdtdx_ctx *ctx, const char *out, const char *in, const 
                          const char *addr_name, const fdtdx_composite *comp, float add, int64_t zsel, int64_t ysel,
                          int64_t xsel, double scale, void *stream);
 
+/* ---- extension: staggered-grid E/H updates -----------------------------------------------------------
+ * The reference has no E/H kernels (its drivers are scalar ping-pong stencils); these entry points have no
+ * counterpart in it and are defined by this library alone (CPU restatement: oracle/fdtd_oracle.c).
+ *
+ * 3-D Yee, six cubes fields[] = {Ex, Ey, Ez, Hx, Hy, Hz} of the context's geometry, outer shell untouched:
+ *   which = 0:  Hx -= c*((Ez[y+1]-Ez) - (Ey[z+1]-Ey)), Hy -= c*((Ex[z+1]-Ex) - (Ez[x+1]-Ez)), Hz -= c*((Ey[x+1]-Ey) - (Ex[y+1]-Ex))
+ *   which = 1:  Ex += c*((Hz-Hz[y-1]) - (Hy-Hy[z-1])), Ey += c*((Hx-Hx[z-1]) - (Hz-Hz[x-1])), Ez += c*((Hy-Hy[x-1]) - (Hx-Hx[y-1]))
+ * on local planes [z_lo, z_hi) (1 <= z_lo, z_hi <= local_planes-1).  fdtdx_yee3d_step = H half step with ch, then
+ * E half step with ce, on every interior plane (one rank). */
+int fdtdx_yee3d_half(fdtdx_ctx *ctx, const char *const fields[6], int which, float coef, uint32_t order, uint64_t z_lo,
+                     uint64_t z_hi, void *stream);
+int fdtdx_yee3d_step(fdtdx_ctx *ctx, const char *const fields[6], float ce, float ch, uint32_t order, void *stream);
+/* 2-D ex/ey/hz on dense [nx][ny] device arrays (ny fastest), `steps` steps numbered t0, t0+1, ...:
+ *   ey[0][j] = t;  ey[i][j] -= ce*(hz[i][j]-hz[i-1][j]) (i>=1);  ex[i][j] -= ce*(hz[i][j]-hz[i][j-1]) (j>=1);
+ *   hz[i][j] -= ch*(((ex[i][j+1]-ex[i][j]) + ey[i+1][j]) - ey[i][j])  (i<nx-1, j<ny-1). */
+int fdtdx_yee2d_steps(int device, float *ex, float *ey, float *hz, uint64_t nx, uint64_t ny, int t0, int steps, float ce,
+                      float ch, uint32_t order, void *stream);
+
 /* Kernel-selection knobs, for tuning and tests: "zchunks" (z-chunks per sweep launch, 0 = auto),
  * "variant" (tile-shape index, -1 = auto), "temporal" (time steps fdtdx_sweep fuses per launch where
  * a fused kernel exists: 1 = as many as there is a kernel for, 2, 3, or 0 = one launch per step),

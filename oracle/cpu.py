@@ -58,9 +58,12 @@ def lib():
         L.oracle_filt.argtypes = [_f32p, sz, sz, sz, sz, sz, sz, sz, ctypes.c_double, ctypes.c_int, sz, sz]
         L.oracle_mul_acc.argtypes = [_f32p, _f32p, _f32p, sz, sz, sz, ctypes.c_int, ctypes.c_int, sz, sz]
         L.oracle_main_step.argtypes = [_f32p, _f32p, _f32p, _f32p, _u64p, sz, sz, sz, sz, ctypes.c_int]
+        L.oracle_yee2d_init.argtypes = [_f32p, _f32p, _f32p, sz, sz]
+        L.oracle_yee2d_step.argtypes = [_f32p, _f32p, _f32p, sz, sz, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int]
+        L.oracle_yee3d_half.argtypes = [ctypes.POINTER(_f32p), ctypes.c_int, sz, sz, sz, ctypes.c_float, ctypes.c_int, sz, sz]
         for f in (L.oracle_init_mt, L.oracle_init_jacobi, L.oracle_star_step, L.oracle_spc13_step,
                   L.oracle_jacobi7_step, L.oracle_run, L.oracle_composite_sweep, L.oracle_inject, L.oracle_filt,
-                  L.oracle_mul_acc, L.oracle_main_step):
+                  L.oracle_mul_acc, L.oracle_main_step, L.oracle_yee2d_init, L.oracle_yee2d_step, L.oracle_yee3d_half):
             f.restype = None
         _lib = L
     return _lib
@@ -157,6 +160,30 @@ def ref_main_step(p0, p1, vel, s, addr):
     nz, ny, nx = p0.shape
     a = np.ascontiguousarray(addr, np.uint64)
     ref().ref_main_step(_p(p0), _p(p1), _p(vel), _p(s), a.ctypes.data_as(ctypes.POINTER(ctypes.c_size_t)), len(a), nz, ny, nx)
+
+
+# extension: E/H updates that the reference does not have (this file's C source is their definition) -------
+def yee2d_init(nx, ny):
+    ex, ey, hz = (np.empty((nx, ny), np.float32) for _ in range(3))
+    lib().oracle_yee2d_init(_p(ex), _p(ey), _p(hz), nx, ny)
+    return ex, ey, hz
+
+
+def yee2d_step(ex, ey, hz, t, ce=0.5, ch=0.7, order=ORDER_CHAIN):
+    nx, ny = ex.shape
+    lib().oracle_yee2d_step(_p(ex), _p(ey), _p(hz), nx, ny, t, ce, ch, order)
+
+
+def yee3d_half(fields, which, coef, order=ORDER_CHAIN, z_lo=None, z_hi=None):
+    """fields = [Ex, Ey, Ez, Hx, Hy, Hz]; which 0: H half step, 1: E half step."""
+    nz, ny, nx = fields[0].shape
+    arr = (_f32p * 6)(*[_p(f) for f in fields])
+    lib().oracle_yee3d_half(arr, which, nz, ny, nx, coef, order, 1 if z_lo is None else z_lo, nz - 1 if z_hi is None else z_hi)
+
+
+def yee3d_step(fields, ce, ch, order=ORDER_CHAIN):
+    yee3d_half(fields, 0, ch, order)
+    yee3d_half(fields, 1, ce, order)
 
 
 # ----------------------------------------------------------------------------------------------

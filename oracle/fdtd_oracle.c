@@ -350,3 +350,86 @@ void oracle_main_step(float *p0, const float *p1, const float *vel, float *sum, 
     oracle_filt(p0, nz, ny, nx, 0, nz / 2, ny / 3, nx / 4, 0.9, order, 0, nz);
     oracle_mul_acc(sum, p0, p1, nz, ny, nx, 4, order, 4, nz - 4);
 }
+
+/* ------------------------------------------------------------------------- */
+/* EXTENSION -- NO REFERENCE ORACLE.  The two kernels below are named by the   */
+/* build target but do not exist in the reference; this file is their only     */
+/* definition ("parity unpinned": nothing of the reference pins them).         */
+/*                                                                             */
+/* 2-D TE-mode update on [NX][NY] arrays (j fastest), the classic ex/ey/hz      */
+/* scheme: per step t                                                           */
+/*   ey[0][j]  = (float)t                                                       */
+/*   ey[i][j] -= 0.5f*(hz[i][j] - hz[i-1][j])          i >= 1                   */
+/*   ex[i][j] -= 0.5f*(hz[i][j] - hz[i][j-1])          j >= 1                   */
+/*   hz[i][j] -= 0.7f*(((ex[i][j+1] - ex[i][j]) + ey[i+1][j]) - ey[i][j])       */
+/*                                                     i < NX-1, j < NY-1       */
+/* ORDER_GOLDEN: separate multiply and subtract; ORDER_CHAIN: a = fmaf(-c,d,a). */
+/* ------------------------------------------------------------------------- */
+void oracle_yee2d_init(float *ex, float *ey, float *hz, size_t nx, size_t ny)
+{
+    for (size_t i = 0; i < nx; i++)
+        for (size_t j = 0; j < ny; j++) {
+            ex[i * ny + j] = ((float)i * (float)(j + 1)) / (float)nx;
+            ey[i * ny + j] = ((float)i * (float)(j + 2)) / (float)ny;
+            hz[i * ny + j] = ((float)i * (float)(j + 3)) / (float)nx;
+        }
+}
+
+void oracle_yee2d_step(float *ex, float *ey, float *hz, size_t nx, size_t ny, int t, float ce, float ch, int order)
+{
+    for (size_t j = 0; j < ny; j++) ey[j] = (float)t;
+#pragma omp parallel for
+    for (size_t i = 1; i < nx; i++)
+        for (size_t j = 0; j < ny; j++) {
+            const float d = hz[i * ny + j] - hz[(i - 1) * ny + j];
+            ey[i * ny + j] = (order == ORDER_GOLDEN) ? ey[i * ny + j] - ce * d : fmaf(-ce, d, ey[i * ny + j]);
+        }
+#pragma omp parallel for
+    for (size_t i = 0; i < nx; i++)
+        for (size_t j = 1; j < ny; j++) {
+            const float d = hz[i * ny + j] - hz[i * ny + j - 1];
+            ex[i * ny + j] = (order == ORDER_GOLDEN) ? ex[i * ny + j] - ce * d : fmaf(-ce, d, ex[i * ny + j]);
+        }
+#pragma omp parallel for
+    for (size_t i = 0; i < nx - 1; i++)
+        for (size_t j = 0; j < ny - 1; j++) {
+            const float d = ((ex[i * ny + j + 1] - ex[i * ny + j]) + ey[(i + 1) * ny + j]) - ey[i * ny + j];
+            hz[i * ny + j] = (order == ORDER_GOLDEN) ? hz[i * ny + j] - ch * d : fmaf(-ch, d, hz[i * ny + j]);
+        }
+}
+
+/* 3-D Yee update, six fields [z][y][x], scalar coefficients, outer shell of every field untouched   */
+/* (perfect conductor box).  One step = H half step then E half step on the interior [1, n-1):        */
+/*   Hx -= ch*((Ez[y+1] - Ez) - (Ey[z+1] - Ey))      Ex += ce*((Hz - Hz[y-1]) - (Hy - Hy[z-1]))       */
+/*   Hy -= ch*((Ex[z+1] - Ex) - (Ez[x+1] - Ez))      Ey += ce*((Hx - Hx[z-1]) - (Hz - Hz[x-1]))       */
+/*   Hz -= ch*((Ey[x+1] - Ey) - (Ex[y+1] - Ex))      Ez += ce*((Hy - Hy[x-1]) - (Hx - Hx[y-1]))       */
+/* f[0..2] = Ex,Ey,Ez, f[3..5] = Hx,Hy,Hz.  which: 0 = H half step, 1 = E half step, on planes         */
+/* [z_lo, z_hi).                                                                                      */
+void oracle_yee3d_half(float *const *f, int which, size_t nz, size_t ny, size_t nx, float coef, int order, size_t z_lo,
+                       size_t z_hi)
+{
+    (void)nz;
+    const ptrdiff_t sx = 1, sy = (ptrdiff_t)nx, sz = (ptrdiff_t)(ny * nx);
+    const float *Ex = f[0], *Ey = f[1], *Ez = f[2], *Hx = f[3], *Hy = f[4], *Hz = f[5];
+#pragma omp parallel for
+    for (size_t z = z_lo; z < z_hi; z++)
+        for (size_t y = 1; y < ny - 1; y++)
+            for (size_t x = 1; x < nx - 1; x++) {
+                const size_t a = IDX(z, y, x, ny, nx);
+                float d[3];
+                float *dst[3];
+                if (which == 0) {
+                    d[0] = (Ez[a + sy] - Ez[a]) - (Ey[a + sz] - Ey[a]);
+                    d[1] = (Ex[a + sz] - Ex[a]) - (Ez[a + sx] - Ez[a]);
+                    d[2] = (Ey[a + sx] - Ey[a]) - (Ex[a + sy] - Ex[a]);
+                    dst[0] = f[3] + a, dst[1] = f[4] + a, dst[2] = f[5] + a;
+                } else {
+                    d[0] = (Hz[a] - Hz[a - sy]) - (Hy[a] - Hy[a - sz]);
+                    d[1] = (Hx[a] - Hx[a - sz]) - (Hz[a] - Hz[a - sx]);
+                    d[2] = (Hy[a] - Hy[a - sx]) - (Hx[a] - Hx[a - sy]);
+                    dst[0] = f[0] + a, dst[1] = f[1] + a, dst[2] = f[2] + a;
+                }
+                const float c = (which == 0) ? -coef : coef;
+                for (int k = 0; k < 3; k++) *dst[k] = (order == ORDER_GOLDEN) ? *dst[k] + c * d[k] : fmaf(c, d[k], *dst[k]);
+            }
+}

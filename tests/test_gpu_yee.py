@@ -1,0 +1,80 @@
+"""EXTENSION -- no reference oracle.  The staggered-grid E/H updates (3-D six-field Yee step, 2-D
+ex/ey/hz) do not exist in the reference; they are defined by oracle/fdtd_oracle.c (oracle_yee3d_half,
+oracle_yee2d_step) and the HIP kernels must reproduce that definition bit for bit in both orders.
+Beyond that, a property the scheme itself offers: the discrete divergence of H is left unchanged by a
+step (div curl = 0 on the staggered grid) up to rounding."""
+import numpy as np
+import pytest
+import torch
+
+from fdtd_amd import Stencil, ORDER_CHAIN, ORDER_GOLDEN
+from fdtd_amd import lib
+
+pytestmark = pytest.mark.gpu
+ORD = {ORDER_CHAIN: 1, ORDER_GOLDEN: 0}
+NAMES = ("ex", "ey", "ez", "hx", "hy", "hz")
+
+
+def fields(shape, seed=3):
+    rng = np.random.default_rng(seed)
+    return [rng.random(shape, dtype=np.float32) for _ in range(6)]
+
+
+def gpu_yee3d(shape, f, steps, order, ce=0.31, ch=0.27):
+    Z, Y, X = shape
+    with Stencil(Z, Y, X, 1) as st:
+        for n, a in zip(NAMES, f):
+            st.mallocCube(n)
+            st.transferCubeToGPU(n, a)
+        for _ in range(steps):
+            st.yee3dStep(NAMES, ce, ch, order)
+        st.sync()
+        out = [np.empty(shape, np.float32) for _ in range(6)]
+        for n, a in zip(NAMES, out):
+            st.transferCubeToCPU(a, n)
+    return out
+
+
+@pytest.mark.parametrize("order", [ORDER_CHAIN, ORDER_GOLDEN])
+@pytest.mark.parametrize("shape", [(3, 3, 3), (9, 14, 21), (20, 37, 260), (40, 9, 513)])
+def test_yee3d_equals_its_cpu_definition(oracle_cpu, shape, order):
+    f = fields(shape)
+    ref = [a.copy() for a in f]
+    for _ in range(4):
+        oracle_cpu.yee3d_step(ref, 0.31, 0.27, order=ORD[order])
+    got = gpu_yee3d(shape, f, 4, order)
+    for n, g, r in zip(NAMES, got, ref):
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32)), n
+
+
+def test_yee3d_fullsize_and_divergence(oracle_cpu):
+    shape = (256, 256, 256)
+    f = fields(shape, seed=5)
+    ref = [a.copy() for a in f]
+    for _ in range(2):
+        oracle_cpu.yee3d_step(ref, 0.31, 0.27, order=1)
+    got = gpu_yee3d(shape, f, 2, ORDER_CHAIN)
+    for n, g, r in zip(NAMES, got, ref):
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32)), n
+
+    def div_h(hx, hy, hz):  # forward differences, like the curl of the H half step, where every cell involved is updated
+        s = np.s_[2:-2, 2:-2, 2:-2]
+        return ((hx[2:-2, 2:-2, 3:-1] - hx[s]) + (hy[2:-2, 3:-1, 2:-2] - hy[s]) + (hz[3:-1, 2:-2, 2:-2] - hz[s])).astype(np.float64)
+    before, after = div_h(*f[3:]), div_h(*got[3:])
+    assert np.abs(after - before).max() < 2e-5  # rounding only: the update adds a discrete curl
+
+
+@pytest.mark.parametrize("order", [ORDER_CHAIN, ORDER_GOLDEN])
+@pytest.mark.parametrize("shape", [(2, 2), (17, 33), (200, 301), (2048, 2048)])
+def test_yee2d_equals_its_cpu_definition(oracle_cpu, shape, order):
+    nx, ny = shape
+    steps = 6 if nx < 2048 else 3
+    ex, ey, hz = oracle_cpu.yee2d_init(nx, ny)
+    dev = [torch.from_numpy(a.copy()).cuda() for a in (ex, ey, hz)]
+    lib.yee2d_steps(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), nx, ny, 0, steps, 0.5, 0.7, order,
+                    stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for t in range(steps):
+        oracle_cpu.yee2d_step(ex, ey, hz, t, 0.5, 0.7, order=ORD[order])
+    for name, d, r in zip(("ex", "ey", "hz"), dev, (ex, ey, hz)):
+        assert np.array_equal(d.cpu().numpy().view(np.uint32), r.view(np.uint32)), name
