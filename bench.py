@@ -34,6 +34,9 @@ VARIANTS = {  # name -> (program kind, radius, reference driver)
     "fdtdspc": ("spc13", 1, "fdtdspc.cu"),
     "jacobi": ("jacobi7", 1, "jacobi.cu"),
     "main": ("composite", 4, "main.cu"),  # sweep + inject + filt + mul (main.cu:149-171), one rank
+    # extensions without a counterpart in the reference (defined by oracle/fdtd_oracle.c):
+    "yee3d": ("yee3d", 1, "none: extension"),  # six-field E/H step, 72 B per cell-step as two half steps
+    "yee2d": ("yee2d", 1, "none: extension"),  # ex/ey/hz on n x n, 36 B per cell-step as two launches (--size 2048)
 }
 BYTES_PER_UPDATE_MAIN = 24.0  # p1, vel, old p0, sum read + p0, sum write
 PEAK_HBM_GBS = 8000.0
@@ -182,8 +185,45 @@ def main():
         return dict(dt=dt, ev_ms=e0.elapsed_time(e1), cells_rank=cells, cells_all=cells, info=info, kind="composite", radius=4,
                     launches=steps)
 
+    def time_yee(kind, steps, warmup):
+        from fdtd_amd import Stencil, lib as flib
+        n = a.n
+        dev = f"cuda:{local_rank}"
+        if kind == "yee3d":
+            st = Stencil(n, n, n, 1, device=local_rank)
+            names = ("ex", "ey", "ez", "hx", "hy", "hz")
+            bufs = {}
+            for i, name in enumerate(names):
+                bufs[name] = torch.rand(int(st.geometry.cube_elems), dtype=torch.float32, device=dev,
+                                        generator=torch.Generator(device=dev).manual_seed(i))
+                st.attachCube(name, bufs[name].data_ptr(), bufs[name].numel() * 4)
+            cs = torch.cuda.current_stream().cuda_stream
+            loop = lambda k: [st.yee3dStep(names, 0.31, 0.27, stream=cs) for _ in range(k)]
+            cells = float(n - 2) ** 3
+            info = "yee3d_half_kernel x2 per step (H half, E half)"
+        else:
+            ex, ey, hz = (torch.rand(n * n, dtype=torch.float32, device=dev) for _ in range(3))
+            cs = torch.cuda.current_stream().cuda_stream
+            loop = lambda k: flib.yee2d_steps(ex.data_ptr(), ey.data_ptr(), hz.data_ptr(), n, n, 0, k, 0.5, 0.7, device=local_rank, stream=cs)
+            cells = float(n) * float(n)
+            info = "yee2d_e_kernel + yee2d_h_kernel per step"
+        loop(warmup)
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        loop(steps)
+        e1.record()
+        barrier()
+        dt = time.perf_counter() - t0
+        return dict(dt=dt, ev_ms=e0.elapsed_time(e1), cells_rank=cells, cells_all=cells, info=info, kind=kind, radius=1, launches=2 * steps)
+
     def time_variant(name, steps, warmup):
         kind, radius, _ = VARIANTS[name]
+        if kind in ("yee3d", "yee2d"):
+            if world != 1:
+                raise SystemExit("the E/H extension variants run on one rank")
+            return time_yee(kind, steps, warmup)
         if kind == "composite":
             if world != 1:
                 raise SystemExit("--variant main runs on one rank")
@@ -253,7 +293,8 @@ def main():
     nlaunch = r["launches"] or a.steps
     steps_per_launch = a.steps / nlaunch
     launch_s = r["ev_ms"] * 1e-3 / nlaunch
-    bpu = BYTES_PER_UPDATE_MAIN if r["kind"] == "composite" else BYTES_PER_UPDATE  # main: per step = 4 launches
+    # bytes per cell-step: main 24 (one fused step); yee3d 72 and yee2d 36 per step of two launches
+    bpu = {"composite": BYTES_PER_UPDATE_MAIN, "yee3d": 72.0, "yee2d": 36.0}.get(r["kind"], BYTES_PER_UPDATE)
     achieved = bpu * r["cells_rank"] * steps_per_launch / launch_s * 1e-9
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
@@ -265,15 +306,19 @@ def main():
         except Exception:
             traffic = None
 
+    grid = [a.n, a.n] if r["kind"] == "yee2d" else [a.n * world, a.n, a.n]
+    if r["kind"] == "yee3d":
+        workload = f"yee3d (extension): six-field E/H step = H half step + E half step, {a.n}^3 fp32 grid, {a.steps} steps"
+    elif r["kind"] == "yee2d":
+        workload = f"yee2d (extension): ex/ey/hz step on a {a.n}x{a.n} fp32 grid, {a.steps} steps"
+    else:
+        workload = (f"{a.variant}: {VARIANTS[a.variant][0]} radius {r['radius']} sweep ({VARIANTS[a.variant][2]}), "
+                    f"{a.n * world}x{a.n}x{a.n} fp32 grid, {a.steps} steps, z-slabs of {a.n} planes per GPU")
     line = {
         "metric": "cell-updates/sec", "value": round(value, 2), "unit": "Gcell/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(r["dt"] / a.steps * 1e3, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{a.variant}: {VARIANTS[a.variant][0]} radius {r['radius']} sweep "
-                               f"({VARIANTS[a.variant][2]}), {a.n * world}x{a.n}x{a.n} fp32 grid, {a.steps} steps, "
-                               f"z-slabs of {a.n} planes per GPU",
-                   "grid": [a.n * world, a.n, a.n], "radius": r["radius"], "parallelism": f"zslab{world}",
-                   "kernel": r["info"]},
+        "config": {"workload": workload, "grid": grid, "radius": r["radius"], "parallelism": f"zslab{world}", "kernel": r["info"]},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": bpu * r["cells_rank"] * steps_per_launch,
@@ -283,12 +328,14 @@ def main():
     if a.all_variants and world == 1:
         others = {}
         for name in sorted(VARIANTS):
-            if name == a.variant or (name == "main" and a.n < 9):
+            if name == a.variant or name in ("main", "yee3d", "yee2d"):
                 continue
             o = time_variant(name, min(a.steps, 200), 5)
             others[name] = round(o["cells_all"] * min(a.steps, 200) / o["dt"] * 1e-9, 1)
         line["other_variants_gcells"] = others
-    if rank == 0 and world == 1 and not a.no_cpu:
+    if r["kind"] in ("yee3d", "yee2d"):
+        line["extension"] = "no counterpart in the reference: defined by oracle/fdtd_oracle.c, parity unpinned"
+    if rank == 0 and world == 1 and not a.no_cpu and r["kind"] not in ("yee3d", "yee2d"):
         try:
             line["cpu_baseline"] = cpu_baseline(r["kind"], r["radius"], a.n)
         except Exception as e:  # the GPU number stands on its own
