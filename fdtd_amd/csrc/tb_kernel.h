@@ -237,6 +237,10 @@ __global__ __launch_bounds__(NW * 64) void tb_r1_kernel(const TbParams p)
         // ---- levels 1..KT: level l at plane pz-l from level l-1 planes pz-l-1, pz-l, pz-l+1 ------
 #pragma unroll
         for (int l = 1; l <= KT; l++) {
+            // Rows closer than l to the tile's edge have no valid level-l value (the neighbouring tile
+            // computes them): a wave all of whose rows are such rows skips the level.  What it leaves in
+            // its queue and publishes is only ever read for rows that are invalid one level up.
+            if (w * RY + RY - 1 < l || w * RY > ROWS - 1 - l) continue;  // uniform
             float4 up[RX], dn[RX], res[RY][RX];
 #pragma unroll
             for (int i = 0; i < RX; i++) {
