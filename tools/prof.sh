@@ -5,6 +5,7 @@
 set -uo pipefail
 TAG="$1"; shift
 OUT="gpurun_out/prof_${TAG}"
+rm -rf "$OUT"  # never mix passes of different builds
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 ARGS=("$@")
