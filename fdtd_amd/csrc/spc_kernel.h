@@ -158,10 +158,17 @@ __global__ __launch_bounds__(TQ *LY) void spc13_sweep_kernel(const SweepParams p
 #pragma unroll
         for (int j = 0; j < RY; j++) {
             const int o = ownl[j];
-            const float4 C = s0[o];
-            const float4 U = s0[o + LPQ], D = s0[o - LPQ];
-            const float4 ZP = sp[o], ZM = sm[o];
-            const float4 ZPU = sp[o + LPQ], ZMD = sm[o - LPQ];
+            // whole-quad reads, kept whole: split into a 12-byte and a 4-byte read (which the compiler
+            // does to feed the lane rotates early) they would be bank conflicts at the 16-byte lane stride
+            auto quad = [](const float4 *q) {
+                f32x4 v = *reinterpret_cast<const f32x4 *>(q);
+                asm("" : "+v"(v));
+                return make_float4(v[0], v[1], v[2], v[3]);
+            };
+            const float4 C = quad(s0 + o);
+            const float4 U = quad(s0 + o + LPQ), D = quad(s0 + o - LPQ);
+            const float4 ZP = quad(sp + o), ZM = quad(sm + o);
+            const float4 ZPU = quad(sp + o + LPQ), ZMD = quad(sm + o - LPQ);
             // The six single cells left/right of those quads belong to the neighbouring lanes'
             // quads: take them from their registers with a DPP wave rotate.  (Read from LDS, 4-byte
             // reads at a 16-byte lane stride are 4-way bank conflicts.)  Only the lanes at the end of
