@@ -1,19 +1,9 @@
-// tb_r1.hip -- shapes of the fused (two or three steps per launch) radius-1 sweep (fdtd1.cu, jacobi.cu).
+// tb_r1_jacobi.hip -- shapes of the fused (two or three steps per launch) radius-1 sweep in jacobi.cu's order (jacobi.cu:31-38).
 #include "tb_kernel.h"
 using namespace fdtdx;
 // the first shape listed for a step count and order is the default (tools/tune.py --tb-variant)
-FDTDX_TB_VARIANT(3, 16, 1, 2, ORD_STAR_CHAIN)
 FDTDX_TB_VARIANT(3, 16, 1, 2, ORD_JACOBI_CHAIN)
-FDTDX_TB_VARIANT(3, 8, 2, 2, ORD_STAR_CHAIN)
 FDTDX_TB_VARIANT(3, 8, 2, 2, ORD_JACOBI_CHAIN)
-FDTDX_TB_VARIANT(2, 8, 3, 2, ORD_STAR_CHAIN)
-FDTDX_TB_VARIANT(2, 8, 2, 2, ORD_STAR_CHAIN)
-FDTDX_TB_VARIANT(2, 8, 4, 2, ORD_STAR_CHAIN)
-FDTDX_TB_VARIANT(2, 4, 6, 2, ORD_STAR_CHAIN)
-FDTDX_TB_VARIANT(2, 4, 4, 2, ORD_STAR_CHAIN)
-FDTDX_TB_VARIANT(2, 5, 4, 2, ORD_STAR_CHAIN)
-FDTDX_TB_VARIANT(2, 6, 4, 2, ORD_STAR_CHAIN)
-FDTDX_TB_VARIANT(2, 6, 3, 2, ORD_STAR_CHAIN)
 FDTDX_TB_VARIANT(2, 8, 3, 2, ORD_JACOBI_CHAIN)
 FDTDX_TB_VARIANT(2, 8, 2, 2, ORD_JACOBI_CHAIN)
 FDTDX_TB_VARIANT(2, 8, 4, 2, ORD_JACOBI_CHAIN)
@@ -22,5 +12,4 @@ FDTDX_TB_VARIANT(2, 4, 4, 2, ORD_JACOBI_CHAIN)
 FDTDX_TB_VARIANT(2, 5, 4, 2, ORD_JACOBI_CHAIN)
 FDTDX_TB_VARIANT(2, 6, 4, 2, ORD_JACOBI_CHAIN)
 FDTDX_TB_VARIANT(2, 6, 3, 2, ORD_JACOBI_CHAIN)
-FDTDX_TB_VARIANT(2, 16, 1, 2, ORD_STAR_CHAIN)
 FDTDX_TB_VARIANT(2, 16, 1, 2, ORD_JACOBI_CHAIN)
