@@ -451,7 +451,7 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
     void (*launch)(const SweepParams &, dim3, hipStream_t) = nullptr;
     int dtq, dly, dry;
     default_shape(prog->kind, r, (int)((ctx->cfg.X + 3) / 4), &dtq, &dly, &dry);
-    if (comp && !sum && ctx->cfg.X >= 128) dtq = 32, dly = 16, dry = 2;  // the update alone (three inputs): measured 8 % ahead of full-row tiles
+    if (comp && ctx->cfg.X >= 128) dtq = 32, dly = 16, dry = 2;  // three or four input streams: measured 5-8 % ahead of full-row tiles
     if (prog->kind == FDTDX_SPC13) {
         const SpcVariantInfo *best = nullptr;
         int idx = 0;
@@ -807,34 +807,59 @@ extern "C" int fdtdx_inject(fdtdx_ctx *ctx, const char *cube, const char *addr_n
     return FDTDX_OK;
 }
 
-// one wave per row (z, y): the whole row if the plane or the row is selected, else the single selected cell.
+// filt (stencil.h:817-823 with main.cu:129-133's selection) touches three thin sets of the planes [z_lo, z_lo+nz):
+// every row of the selected z plane and the selected row of every other plane (one wave per row: blocks from
+// `cell_blocks` on), and one cell of every remaining row (one LANE per row: blocks below `cell_blocks`).
 // With `sum` set, the scaled cells that are interior cells also get their product added (sum += cube*other):
 // the fused step leaves exactly these cells to this kernel.
-__global__ void filt_planes_kernel(float *cube, long long plane, int px, int nx, int ny, long long zg0, long long z_lo, long long nrows,
+__global__ void filt_planes_kernel(float *cube, long long plane, int px, int nx, int ny, long long zg0, long long z_lo, long long nz,
                                    long long zsel, long long ysel, long long xsel, double scale, int golden, float *sum, const float *other,
-                                   int h, long long mz_lo, long long mz_hi)
+                                   int h, long long mz_lo, long long mz_hi, unsigned cell_blocks)
 {
-    const long long row = (long long)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
-    if (row >= nrows) return;
-    const int lane = threadIdx.x & 63;
-    const long long z = z_lo + row / ny;
-    const int y = (int)(row % ny);
-    float *r = cube + z * plane + (long long)y * px;
     const float sf = (float)scale;
-    const bool rin = sum && z >= mz_lo && z < mz_hi && y >= h && y < ny - h;
-    auto one = [&](int x) {
-        const float v = golden ? (float)((double)r[x] * scale) : r[x] * sf;
-        r[x] = v;
-        if (rin && x >= h && x < nx - h) {
-            const long long a = z * plane + (long long)y * px + x;
+    const long long zl = zsel - zg0;  // the selected plane in local numbering
+    const bool zin = zl >= z_lo && zl < z_lo + nz, yin = ysel >= 0 && ysel < ny;
+    auto one = [&](long long z, int y, int x) {
+        const long long a = z * plane + (long long)y * px + x;
+        const float v = golden ? (float)((double)cube[a] * scale) : cube[a] * sf;
+        cube[a] = v;
+        if (sum && z >= mz_lo && z < mz_hi && y >= h && y < ny - h && x >= h && x < nx - h)
             sum[a] = golden ? sum[a] + v * other[a] : __builtin_fmaf(v, other[a], sum[a]);
-        }
     };
-    if (zg0 + z == zsel || y == ysel) {
-        for (int x = lane; x < nx; x += 64) one(x);
-    } else if (lane == 0 && xsel >= 0 && xsel < nx) {
-        one((int)xsel);
+    if (blockIdx.x < cell_blocks) {
+        const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (row >= nz * ny || xsel < 0 || xsel >= nx) return;
+        const long long z = z_lo + row / ny;
+        const int y = (int)(row % ny);
+        if (z != zl && y != ysel) one(z, y, (int)xsel);
+        return;
     }
+    const long long nwz = zin ? ny : 0;
+    const long long w = (long long)(blockIdx.x - cell_blocks) * (blockDim.x / 64) + (threadIdx.x >> 6);
+    long long z;
+    int y;
+    if (w < nwz) {
+        z = zl, y = (int)w;
+    } else {
+        const long long q = w - nwz;  // q-th plane of the range that is not the selected one
+        if (!yin || q >= nz - (zin ? 1 : 0)) return;
+        z = z_lo + q + ((zin && z_lo + q >= zl) ? 1 : 0), y = (int)ysel;
+    }
+    for (int x = threadIdx.x & 63; x < nx; x += 64) one(z, y, x);
+}
+
+static int launch_filt(fdtdx_ctx *ctx, float *pc, uint64_t z_lo, uint64_t z_hi, int64_t zsel, int64_t ysel, int64_t xsel, double scale, int golden,
+                       float *sum, const float *other, int h, uint64_t mz_lo, uint64_t mz_hi, hipStream_t s)
+{
+    const fdtdx_geometry &g = ctx->g;
+    const long long nz = (long long)(z_hi - z_lo), ny = (long long)ctx->cfg.Y;
+    const long long cell_blocks = (nz * ny + 255) / 256, row_blocks = (ny + nz + 3) / 4;
+    if (cell_blocks + row_blocks > 0x7fffffffLL) return fail(FDTDX_ERR_UNSUPPORTED, "grid too large");
+    hipLaunchKernelGGL(filt_planes_kernel, dim3((unsigned)(cell_blocks + row_blocks)), dim3(256), 0, s, pc, (long long)g.plane, (int)g.pitch_x,
+                       (int)ctx->cfg.X, (int)ny, (long long)g.first_global, (long long)z_lo, nz, (long long)zsel, (long long)ysel, (long long)xsel,
+                       scale, golden, sum, other, h, (long long)mz_lo, (long long)mz_hi, (unsigned)cell_blocks);
+    HIP_TRY(hipGetLastError());
+    return FDTDX_OK;
 }
 
 __global__ void gather_kernel(float *saved, const float *cube, const uint64_t *addr, uint64_t n)
@@ -867,15 +892,7 @@ extern "C" int fdtdx_filt_planes(fdtdx_ctx *ctx, const char *cube, int64_t zsel,
     if ((rc = owned_range(ctx, z_lo, z_hi, "filt"))) return rc;
     if (order != FDTDX_ORDER_CHAIN && order != FDTDX_ORDER_GOLDEN) return fail(FDTDX_ERR_INVALID, "unknown order %u", order);
     if (z_lo == z_hi) return FDTDX_OK;
-    const fdtdx_geometry &g = ctx->g;
-    const long long nrows = (long long)(z_hi - z_lo) * (long long)ctx->cfg.Y;
-    const long long blocks = (nrows + 3) / 4;
-    if (blocks > 0x7fffffffLL) return fail(FDTDX_ERR_UNSUPPORTED, "grid too large");
-    hipLaunchKernelGGL(filt_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pc, (long long)g.plane, (int)g.pitch_x,
-                       (int)ctx->cfg.X, (int)ctx->cfg.Y, (long long)g.first_global, (long long)z_lo, nrows, (long long)zsel, (long long)ysel,
-                       (long long)xsel, scale, order == FDTDX_ORDER_GOLDEN ? 1 : 0, (float *)nullptr, (const float *)nullptr, 0, 0LL, 0LL);
-    HIP_TRY(hipGetLastError());
-    return FDTDX_OK;
+    return launch_filt(ctx, pc, z_lo, z_hi, zsel, ysel, xsel, scale, order == FDTDX_ORDER_GOLDEN ? 1 : 0, nullptr, nullptr, 0, 0, 0, (hipStream_t)stream);
 }
 
 // One whole step of main.cu:160-163 on the planes this rank owns, with the product-accumulate folded
@@ -913,15 +930,7 @@ extern "C" int fdtdx_composite_step(fdtdx_ctx *ctx, const char *out, const char 
     const int64_t sel[3] = {zsel, ysel, xsel};
     if ((rc = launch_sweep(ctx, po, pi, nullptr, lo, hi, stream, comp, pv, ps, sel))) return rc;
     if ((rc = fdtdx_inject(ctx, out, addr_name, add, olo, ohi, stream))) return rc;
-    if (ohi > olo) {
-        const long long nrows = (long long)(ohi - olo) * (long long)ctx->cfg.Y;
-        const long long blocks = (nrows + 3) / 4;
-        if (blocks > 0x7fffffffLL) return fail(FDTDX_ERR_UNSUPPORTED, "grid too large");
-        hipLaunchKernelGGL(filt_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, po, (long long)g.plane, (int)g.pitch_x, (int)ctx->cfg.X,
-                           (int)ctx->cfg.Y, (long long)g.first_global, (long long)olo, nrows, (long long)zsel, (long long)ysel, (long long)xsel,
-                           scale, golden, ps, (const float *)pi, (int)r, (long long)lo, (long long)hi);
-        HIP_TRY(hipGetLastError());
-    }
+    if (ohi > olo && (rc = launch_filt(ctx, po, olo, ohi, zsel, ysel, xsel, scale, golden, ps, pi, (int)r, lo, hi, s))) return rc;
     if (n) {
         hipLaunchKernelGGL(redo_product_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ps, (const float *)ctx->saved_sum,
                            (const float *)po, (const float *)pi, (const uint64_t *)it->second.ptr, n, (long long)g.plane, (int)g.pitch_x,

@@ -130,15 +130,15 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
 #pragma unroll
         for (int j = 0; j < RY; j++) {
             vq_cur[j] = cs.vq[j];
-            cs.vq[j] = buf_ld4(rv, L.soff[j]);
+            cs.vq[j] = buf_ld4s(rv, L.soff[j]);
             sq_cur[j] = cs.sq[j];
-            cs.sq[j] = buf_ld4(rs, L.soff[j]);
+            cs.sq[j] = buf_ld4s(rs, L.soff[j]);
         }
     }
 #pragma unroll
     for (int k = 0; k < NHK; k++) hv[k] = buf_ld4(rc, L.hgoff[k]);
 #pragma unroll
-    for (int j = 0; j < RY; j++) eo[j] = buf_ld4(ron, L.eoff[j]);
+    for (int j = 0; j < RY; j++) eo[j] = is_composite(ORDER) ? buf_ld4s(ron, L.eoff[j]) : buf_ld4(ron, L.eoff[j]);
     __syncthreads();
 
     const float c0 = c[0], cxp = c[1], cxm = c[2], cyp = c[3], cym = c[4], czp = c[5], czm = c[6];
@@ -388,8 +388,8 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
         cs.ps = p.sum ? p.sum + (long long)zs * p.plane : nullptr;
 #pragma unroll
         for (int j = 0; j < RY; j++) {
-            cs.vq[j] = buf_ld4(make_rsrc(cs.pv, plane_bytes), L.soff[j]);
-            cs.sq[j] = buf_ld4(make_rsrc(cs.ps, p.sum ? plane_bytes : 0u), L.soff[j]);
+            cs.vq[j] = buf_ld4s(make_rsrc(cs.pv, plane_bytes), L.soff[j]);
+            cs.sq[j] = buf_ld4s(make_rsrc(cs.ps, p.sum ? plane_bytes : 0u), L.soff[j]);
         }
     }
 

@@ -75,6 +75,15 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned vof
     const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
     return make_float4(f[0], f[1], f[2], f[3]);
 }
+// the same load for data read once per sweep (second inputs, old output): streamed past the caches
+#ifndef FDTDX_STREAM_AUX
+#define FDTDX_STREAM_AUX 2
+#endif
+__device__ __forceinline__ float4 buf_ld4s(__amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, FDTDX_STREAM_AUX));
+    return make_float4(f[0], f[1], f[2], f[3]);
+}
 __device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned voff, float a, float b, float c, float d)
 {
     f32x4 f;
