@@ -22,6 +22,20 @@ struct YeeParams {
     float coef;
 };
 
+// the updated fields are read once and written once per half step and not touched again before the next
+// half step: streamed past the caches, which then hold the differenced fields' neighbour lines
+__device__ __forceinline__ float4 ld4_stream(const float *p)
+{
+    const f32x4 f = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+    return make_float4(f[0], f[1], f[2], f[3]);
+}
+__device__ __forceinline__ void st4_stream(float *p, const float (&v)[4])
+{
+    f32x4 f;
+    f[0] = v[0], f[1] = v[1], f[2] = v[2], f[3] = v[3];
+    __builtin_nontemporal_store(f, reinterpret_cast<f32x4 *>(p));
+}
+
 __device__ __forceinline__ float upd(float a, float c, float d, int golden) { return golden ? a + c * d : __builtin_fmaf(c, d, a); }
 
 // WHICH = 0: H -= ch*curl(E) with forward differences; WHICH = 1: E += ce*curl(H) with backward differences.
@@ -67,7 +81,7 @@ __global__ __launch_bounds__(256) void yee3d_half_kernel(const YeeParams p)
             cx[0] = c0[1], cx[1] = c0[2], cx[2] = c0[3], cx[3] = Cxn;
             bx[0] = b0[1], bx[1] = b0[2], bx[2] = b0[3], bx[3] = Bxn;
         }
-        float4 u4 = ld4(U + a), v4 = ld4(V + a), w4 = ld4(W + a);
+        float4 u4 = ld4_stream(U + a), v4 = ld4_stream(V + a), w4 = ld4_stream(W + a);
         float u[4] = {u4.x, u4.y, u4.z, u4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w}, w[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -83,9 +97,7 @@ __global__ __launch_bounds__(256) void yee3d_half_kernel(const YeeParams p)
             }
             if (m[i]) u[i] = upd(u[i], c, du, GOLDEN), v[i] = upd(v[i], c, dv, GOLDEN), w[i] = upd(w[i], c, dw, GOLDEN);
         }
-        *reinterpret_cast<float4 *>(U + a) = make_float4(u[0], u[1], u[2], u[3]);
-        *reinterpret_cast<float4 *>(V + a) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4 *>(W + a) = make_float4(w[0], w[1], w[2], w[3]);
+        st4_stream(U + a, u), st4_stream(V + a, v), st4_stream(W + a, w);
         if (WHICH) {
             Az = A0, Bz = B0;  // the current plane is the next one's z-1
             if (z + 1 < ze) A0 = ld4(A + a + p.plane), B0 = ld4(B + a + p.plane);
