@@ -397,8 +397,8 @@ static void default_shape(int kind, int r, int nq, int *tq, int *ly, int *ry)
         return;
     }
     switch (r) {
-    case 5: *tq = 32, *ly = 16, *ry = 2; break;
-    case 6: *tq = 32, *ly = 16, *ry = 2; break;
+    case 5: *tq = 64, *ly = 16, *ry = 1; break;
+    case 6: *tq = 64, *ly = 16, *ry = 1; break;
     case 7: *tq = 32, *ly = 16, *ry = 1; break;
     default: *tq = 32, *ly = 32, *ry = 1; break;
     }
@@ -545,7 +545,8 @@ static const TbVariantInfo *pick_tb(const fdtdx_ctx *ctx, const fdtdx_program *p
 {
     if (prog->order != FDTDX_ORDER_CHAIN) return nullptr;
     int ord;
-    if (prog->kind == FDTDX_STAR && prog->radius == 1)
+    const int radius = prog->kind == FDTDX_STAR ? (int)prog->radius : 1;
+    if (prog->kind == FDTDX_STAR)
         ord = ORD_STAR_CHAIN;
     else if (prog->kind == FDTDX_JACOBI7)
         ord = ORD_JACOBI_CHAIN;
@@ -555,7 +556,7 @@ static const TbVariantInfo *pick_tb(const fdtdx_ctx *ctx, const fdtdx_program *p
     int idx = 0;
     for (int i = 0; i < num_tb_variants(); i++) {
         const TbVariantInfo *v = tb_variant(i);
-        if (v->order != ord || v->kt != kt) continue;
+        if (v->order != ord || v->kt != kt || v->radius != radius) continue;
         if (ctx->opt_tb_variant >= 0 ? idx == ctx->opt_tb_variant : !best) best = v;
         idx++;
     }
@@ -575,8 +576,9 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
     p.zg0 = (int)g.first_global, p.nzg = (int)ctx->cfg.Z;
     p.z_lo = (int)z_lo, p.z_hi = (int)z_hi;
     memcpy(p.c, prog->coef, 7 * sizeof(float));
-    const int owned = v->nw * v->ry - 2 * v->kt;
-    p.gy = (p.ny - 2 + owned - 1) / owned;
+    const int reach = v->kt * v->radius;  // cells a fused launch reaches on each side
+    const int owned = v->nw * v->ry - 2 * reach;
+    p.gy = (p.ny - 2 * v->radius + owned - 1) / owned;
     const int nq = (p.nx + 3) / 4, tq = 64 * v->rx;
     if (nq <= tq)
         p.gx = 1, p.qstep = tq, p.qbase = 0;
@@ -594,7 +596,7 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
         chunks = 1;
         for (long long cnt = 1; cnt <= std::max<long long>(1, nz / 16) && cnt * tiles <= 4096; cnt++) {
             const long long len = (nz + cnt - 1) / cnt, n = tiles * ((nz + len - 1) / len);
-            const double eff = (double)n / (double)((n + 255) / 256 * 256) * (double)len / (double)(len + 4 + v->kt);
+            const double eff = (double)n / (double)((n + 255) / 256 * 256) * (double)len / (double)(len + 4 + reach);
             if (eff > best + 1e-9) best = eff, chunks = cnt;
         }
     }
@@ -605,8 +607,8 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
     v->launch(p, dim3((unsigned)(p.gx * p.gy * p.gz)), (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     ctx->launches++;
-    snprintf(ctx->last_fused, sizeof(ctx->last_fused), "fused%d kind=%u r=1 waves=%d rows/wave=%d quads/lane/row=%d tile_rows=%d(stored %d) threads=%d lds=%d grid=%dx%dx%d zchunk=%d",
-             v->kt, prog->kind, v->nw, v->ry, v->rx, v->nw * v->ry, owned, v->threads, v->lds_bytes, p.gx, p.gy, p.gz, p.zchunk);
+    snprintf(ctx->last_fused, sizeof(ctx->last_fused), "fused%d kind=%u r=%d waves=%d rows/wave=%d quads/lane/row=%d tile_rows=%d(stored %d) threads=%d lds=%d grid=%dx%dx%d zchunk=%d",
+             v->kt, prog->kind, v->radius, v->nw, v->ry, v->rx, v->nw * v->ry, owned, v->threads, v->lds_bytes, p.gx, p.gy, p.gz, p.zchunk);
     return FDTDX_OK;
 }
 
@@ -624,12 +626,13 @@ extern "C" int fdtdx_propagate_fused_planes(fdtdx_ctx *ctx, const char *out, con
     // (shell cells are only read, interior cells only written)
     if (po == pi || pm == pi || (po == pm && nsteps == 2)) return fail(FDTDX_ERR_INVALID, "fused sweep cannot write a cube it reads");
     const TbVariantInfo *tb = pick_tb(ctx, prog, (int)nsteps);
-    if (!tb) return fail(FDTDX_ERR_UNSUPPORTED, "no fused kernel for this program (radius 1, device order only)");
+    if (!tb) return fail(FDTDX_ERR_UNSUPPORTED, "no fused kernel for this program (device order; radius 1: 2 or 3 steps, radius 2: 2 steps)");
     const fdtdx_geometry &g = ctx->g;
-    // k steps need k planes of support on each side: ghost planes, or the global shell
-    const uint64_t need_lo = g.ghost_lo ? nsteps : 1, need_hi = g.ghost_hi ? nsteps : 1;
-    if ((g.ghost_lo && g.ghost_lo < nsteps) || (g.ghost_hi && g.ghost_hi < nsteps) || z_lo < need_lo || z_hi > g.local_planes - need_hi || z_lo > z_hi)
-        return fail(FDTDX_ERR_INVALID, "fused plane range [%llu,%llu) needs %u ghost planes towards a neighbour", (unsigned long long)z_lo, (unsigned long long)z_hi, nsteps);
+    // k steps of radius r need k*r planes of support on each side: ghost planes, or the global shell (r planes)
+    const uint64_t reach = (uint64_t)nsteps * r;
+    const uint64_t need_lo = g.ghost_lo ? reach : r, need_hi = g.ghost_hi ? reach : r;
+    if ((g.ghost_lo && g.ghost_lo < reach) || (g.ghost_hi && g.ghost_hi < reach) || z_lo < need_lo || z_hi > g.local_planes - need_hi || z_lo > z_hi)
+        return fail(FDTDX_ERR_INVALID, "fused plane range [%llu,%llu) needs %llu ghost planes towards a neighbour", (unsigned long long)z_lo, (unsigned long long)z_hi, (unsigned long long)reach);
     return launch_tb(ctx, tb, po, pi, pm, prog, z_lo, z_hi, stream);
 }
 
@@ -671,7 +674,7 @@ extern "C" int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const f
         for (uint32_t k = 0; k < hops; k++) {
             float *out = (done % 2 == 0) ? pa : pb;
             const float *in = (done % 2 == 0) ? pb : pa;
-            rc = launch_tb(ctx, tb, out, in, out, prog, 1, g.local_planes - 1, stream);
+            rc = launch_tb(ctx, tb, out, in, out, prog, lo, hi, stream);
             if (rc) return rc;
             done += 3;
         }
@@ -685,7 +688,7 @@ extern "C" int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const f
             HIP_TRY(hipMemcpyAsync(ctx->tb_scratch, pb, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
             float *cur = pb, *oth = ctx->tb_scratch;
             for (uint32_t k = 0; k < pairs; k++) {
-                rc = launch_tb(ctx, tb, oth, cur, pa, prog, 1, g.local_planes - 1, stream);
+                rc = launch_tb(ctx, tb, oth, cur, pa, prog, lo, hi, stream);
                 if (rc) return rc;
                 std::swap(cur, oth);
             }

@@ -310,6 +310,7 @@ __global__ __launch_bounds__(NW * 64) void tb_r1_kernel(const TbParams p)
 struct TbVariantInfo {
     int order;  // ORD_STAR_CHAIN | ORD_JACOBI_CHAIN
     int kt;     // fused steps per launch
+    int radius; // 1 (tb_r1_kernel) or 2..4 (tb_rm_kernel)
     int nw, ry, rx, threads, lds_bytes;
     void (*launch)(const TbParams &, dim3 grid, hipStream_t);
 };
@@ -330,6 +331,7 @@ struct TbRegistrar {
         TbVariantInfo v;
         v.order = ORDER;
         v.kt = KT;
+        v.radius = 1;
         v.nw = NW;
         v.ry = RY;
         v.rx = RX;

@@ -100,9 +100,10 @@ class HipSlabBackend:
 
     def can_fuse(self, program):
         """Deepest fusion the library has a kernel for (0: none)."""
-        ok = (program.order == _lib.ORDER_CHAIN and program.kind in (_lib.STAR, _lib.JACOBI7)
-              and (program.kind == _lib.JACOBI7 or program.radius == 1))
-        return 3 if ok else 0
+        if program.order != _lib.ORDER_CHAIN or program.kind not in (_lib.STAR, _lib.JACOBI7):
+            return 0
+        radius = program.radius if program.kind == _lib.STAR else 1
+        return {1: 3, 2: 2}.get(radius, 0)  # tb_kernel.h: radius 1, two or three steps; tbm_kernel.h: radius 2, two steps
 
     def copy_cube(self, dst, src):
         self.bufs[dst].copy_(self.bufs[src])
@@ -214,12 +215,12 @@ class SlabRunner:
 
     def fusable(self):
         """Steps per launch this slab can fuse: the deepest fused kernel the backend has for the
-        program, limited towards a neighbour by the ghost depth (context created with M >= 2 or 3
-        for a radius-1 program); 0 if none."""
+        program, limited towards a neighbour by the ghost depth (k steps of radius r need k*r ghost
+        planes: context created with M >= 2 or 3 for a radius-1 program, 4 for radius 2); 0 if none."""
         can = getattr(self.b, "can_fuse", None)
-        k = int(can(self.prog)) if can and self.radius == 1 else 0
+        k = int(can(self.prog)) if can else 0
         if self.has_lo or self.has_hi:
-            k = min(k, self.M)
+            k = min(k, self.M // self.radius)
         return k if k >= 2 else 0
 
     def run(self, a, b, steps, fuse=True):

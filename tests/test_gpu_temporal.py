@@ -10,7 +10,7 @@ from fdtd_amd import Stencil, make_program
 pytestmark = pytest.mark.gpu
 
 
-def run(cpu, kind, shape, steps, tb_variant=-1, tb_zchunks=0, temporal=1):
+def run(cpu, kind, shape, steps, tb_variant=-1, tb_zchunks=0, temporal=1, M=1):
     Z, Y, X = shape
     if kind == "jacobi7":
         a = cpu.init_jacobi(Z, Y, X)
@@ -18,8 +18,8 @@ def run(cpu, kind, shape, steps, tb_variant=-1, tb_zchunks=0, temporal=1):
     else:
         a, b = cpu.init_mt(Z, Y, X)
     ca, cb = a.copy(), b.copy()
-    cpu.run(kind, ca, cb, steps, M=1, order=cpu.ORDER_CHAIN)
-    with Stencil(Z, Y, X, 1) as st:
+    cpu.run(kind, ca, cb, steps, M=M, order=cpu.ORDER_CHAIN)
+    with Stencil(Z, Y, X, M) as st:
         st.mallocCube("p0")
         st.mallocCube("p1")
         st.transferCubeToGPU("p0", a)
@@ -27,7 +27,7 @@ def run(cpu, kind, shape, steps, tb_variant=-1, tb_zchunks=0, temporal=1):
         st.setOption("temporal", temporal)
         st.setOption("tb_variant", tb_variant)
         st.setOption("tb_zchunks", tb_zchunks)
-        st.sweep("p0", "p1", make_program(kind, radius=1), steps)
+        st.sweep("p0", "p1", make_program(kind, radius=M), steps)
         st.sync()
         ga, gb = np.empty_like(a), np.empty_like(b)
         st.transferCubeToCPU(ga, "p0")
@@ -72,21 +72,34 @@ def test_fused_wide_rows_are_cut_into_x_tiles(oracle_cpu, kt, kind, X):
     assert f"fused{kt}" in info
 
 
+@pytest.mark.parametrize("steps", [4, 5, 6, 7, 8, 9, 11])
+def test_fused_radius2_step_counts(oracle_cpu, steps):
+    """fdtd2's update fused two steps per launch (tbm_kernel.h): several y tiles and z chunks, ragged x."""
+    info = run(oracle_cpu, "star", (17, 61, 509), steps, tb_zchunks=2, M=2)
+    assert "fused2" in info and "r=2" in info
+
+
+@pytest.mark.parametrize("shape", [(5, 5, 5), (7, 9, 11), (9, 20, 21), (40, 19, 300), (9, 130, 64), (31, 9, 40), (9, 30, 513), (9, 30, 1024),
+                                   (9, 30, 1531)])
+def test_fused_radius2_small_ragged_wide(oracle_cpu, shape):
+    run(oracle_cpu, "star", shape, 7, M=2)
+
+
 def test_temporal_off_equals_on(oracle_cpu):
     info = run(oracle_cpu, "star", (12, 40, 256), 8, temporal=0)
     assert "fused" not in info
 
 
-@pytest.mark.parametrize("kind,steps", [("star", 8), ("jacobi7", 7), ("star", 11)])
-@pytest.mark.parametrize("G", [2, 3])
-def test_fused_on_two_slabs_equals_one(oracle_cpu, G, kind, steps):
-    """Fused hops on a 2-way z split (ghost depth G = steps per launch, one exchange per hop) on one
+@pytest.mark.parametrize("kind,steps,G,R", [("star", 8, 2, 1), ("jacobi7", 7, 2, 1), ("star", 11, 2, 1), ("star", 8, 3, 1),
+                                            ("jacobi7", 7, 3, 1), ("star", 11, 3, 1), ("star", 9, 4, 2), ("star", 8, 4, 2)])
+def test_fused_on_two_slabs_equals_one(oracle_cpu, G, kind, steps, R):
+    """Fused hops on a 2-way z split (ghost depth G = steps per launch x radius R, one exchange per hop) on one
     GPU: the two slabs run in this process and trade ghost planes by device copies.  Equal to the
     oracle's undecomposed step-by-step result bit for bit."""
     import torch
     from fdtd_amd.slab import HipSlabBackend, SlabRunner
     Z, Y, X = 48, 75, 512
-    prog = make_program(kind, radius=1)
+    prog = make_program(kind, radius=R)
     if kind == "jacobi7":
         a = oracle_cpu.init_jacobi(Z, Y, X)
         b = a.copy()
@@ -102,7 +115,7 @@ def test_fused_on_two_slabs_equals_one(oracle_cpu, G, kind, steps):
         be.alloc("c")
         be.copy_cube("c", "p1")
     runs = [SlabRunner(be, G, prog, r, 2) for r, be in enumerate(bes)]
-    assert all(r.fusable() == G for r in runs)
+    assert all(r.fusable() == G // R for r in runs)
 
     def exchange(name):
         l0 = runs[0].local
@@ -116,7 +129,7 @@ def test_fused_on_two_slabs_equals_one(oracle_cpu, G, kind, steps):
 
     def hop(out, inp, mid):
         for run in runs:
-            run.b.sweep_fused(out, inp, mid, prog, G, run.z_lo, run.z_hi)
+            run.b.sweep_fused(out, inp, mid, prog, G // R, run.z_lo, run.z_hi)
         exchange(out)
 
     done = 0
@@ -140,7 +153,7 @@ def test_fused_on_two_slabs_equals_one(oracle_cpu, G, kind, steps):
     torch.cuda.synchronize()
     got0 = np.concatenate([be.st.downloadOwned("p0") for be in bes], axis=0)
     got1 = np.concatenate([be.st.downloadOwned("p1") for be in bes], axis=0)
-    oracle_cpu.run(kind, a, b, steps, M=1, order=oracle_cpu.ORDER_CHAIN)
+    oracle_cpu.run(kind, a, b, steps, M=R, order=oracle_cpu.ORDER_CHAIN)
     for name, got, ref in (("p0", got0, a), ("p1", got1, b)):
         bad = np.argwhere(got.view(np.uint32) != ref.view(np.uint32))
         assert len(bad) == 0, f"{name}: {len(bad)} cells differ, first {bad[:4].tolist()} last {bad[-2:].tolist()}"

@@ -53,7 +53,7 @@ class OracleSlabBackend:
         self.view3(out)[z_lo:z_hi, :, :self.X] = dst[z_lo:z_hi]
 
     def sweep_fused(self, out, inp, mid, program, k, z_lo, z_hi):
-        """k steps the slow way.  Level l is computed on [z_lo-(k-l), z_hi+(k-l)) clipped to the
+        """k steps of radius R the slow way.  Level l is computed on [z_lo-(k-l)R, z_hi+(k-l)R) clipped to the
         interior planes of the GLOBAL grid, into a copy of the cube whose shell that level sees:
         `mid` for odd levels, `inp` for even ones, `out` itself for the last."""
         if z_hi <= z_lo:
@@ -61,13 +61,14 @@ class OracleSlabBackend:
         kind = {lib.STAR: "star", lib.JACOBI7: "jacobi7"}[program.kind]
         g = self.g
         gz0, Zg = int(g.first_global), self.Zg
+        R = program.radius if program.kind == lib.STAR else 1
         cur = np.ascontiguousarray(self.view3(inp)[:, :, :self.X])
         for l in range(1, k + 1):
             shell = out if l == k else (mid if l % 2 == 1 else inp)
             nxt = np.ascontiguousarray(self.view3(shell)[:, :, :self.X])
-            lo = max(z_lo - (k - l), 1 - gz0)
-            hi = min(z_hi + (k - l), Zg - 1 - gz0)
-            self.cpu.step(kind, nxt, cur, M=1, order=self.cpu.ORDER_CHAIN, z_lo=lo, z_hi=hi)
+            lo = max(z_lo - (k - l) * R, R - gz0)
+            hi = min(z_hi + (k - l) * R, Zg - R - gz0)
+            self.cpu.step(kind, nxt, cur, M=R, order=self.cpu.ORDER_CHAIN, z_lo=lo, z_hi=hi)
             cur = nxt
         self.view3(out)[z_lo:z_hi, :, :self.X] = cur[z_lo:z_hi]
 
@@ -136,7 +137,7 @@ def _worker(rank, world, port, kind, M, shape, steps, q, ghost=None):
     else:
         a, b = cpu.init_mt(Z, Y, X)
     be = OracleSlabBackend(cpu, Z, Y, X, ghost or M, rank, world)
-    be.fuse = 3 if ghost is not None else 0
+    be.fuse = (3 if M == 1 else 2) if ghost is not None else 0
     g = be.g
     lo, n = int(g.first_global), int(g.local_planes)
     be.alloc("p0")
@@ -248,21 +249,23 @@ def test_decomposition_invariance(oracle_cpu, world, kind, M, shape, steps):
     assert np.array_equal(got1.view(np.uint32), b.view(np.uint32))
 
 
-@pytest.mark.parametrize("world,kind,shape,steps,ghost", [
-    (2, "star", (16, 9, 11), 6, 2),
-    (2, "star", (16, 9, 11), 9, 2),
-    (3, "jacobi7", (23, 8, 10), 8, 2),
-    (2, "star", (14, 7, 9), 11, 2),
-    (2, "star", (16, 9, 11), 7, 3),
-    (2, "star", (18, 7, 9), 12, 3),
-    (3, "jacobi7", (26, 8, 10), 11, 3),
+@pytest.mark.parametrize("world,kind,shape,steps,ghost,M", [
+    (2, "star", (16, 9, 11), 6, 2, 1),
+    (2, "star", (16, 9, 11), 9, 2, 1),
+    (3, "jacobi7", (23, 8, 10), 8, 2, 1),
+    (2, "star", (14, 7, 9), 11, 2, 1),
+    (2, "star", (16, 9, 11), 7, 3, 1),
+    (2, "star", (18, 7, 9), 12, 3, 1),
+    (3, "jacobi7", (26, 8, 10), 11, 3, 1),
+    (2, "star", (22, 9, 11), 7, 4, 2),   # radius 2: two steps per exchange of four planes
+    (3, "star", (31, 9, 10), 8, 4, 2),
 ])
-def test_fused_hops_on_slabs(oracle_cpu, world, kind, shape, steps, ghost):
-    """Two or three steps per exchange (ghost depth 2 or 3) equal the undecomposed step-by-step update."""
+def test_fused_hops_on_slabs(oracle_cpu, world, kind, shape, steps, ghost, M):
+    """Two or three steps per exchange (ghost depth = steps x radius) equal the undecomposed step-by-step update."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, 1, shape, steps, q, ghost)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, M, shape, steps, q, ghost)) for r in range(world)]
     for p in procs:
         p.start()
     parts = [q.get(timeout=120) for _ in range(world)]
@@ -279,7 +282,7 @@ def test_fused_hops_on_slabs(oracle_cpu, world, kind, shape, steps, ghost):
         b = a.copy()
     else:
         a, b = oracle_cpu.init_mt(Z, Y, X)
-    oracle_cpu.run(kind, a, b, steps, M=1, order=oracle_cpu.ORDER_CHAIN)
+    oracle_cpu.run(kind, a, b, steps, M=M, order=oracle_cpu.ORDER_CHAIN)
     assert np.array_equal(got0.view(np.uint32), a.view(np.uint32))
     assert np.array_equal(got1.view(np.uint32), b.view(np.uint32))
 

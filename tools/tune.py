@@ -42,6 +42,11 @@ def main():
                 prog = make_program(kind, radius=M)
                 cells = float(n - 2 * M) ** 3
                 vlist = [int(x) for x in a.variants.split(',')] if a.variants else None
+                # the device needs 15-30 ms of continuous work after the idle spell of initMt before its
+                # clocks settle; without this the first shapes timed look up to 1.6x slower than they are
+                for _ in range(8):
+                    st.sweep("p0", "p1", prog, 60, stream)
+                torch.cuda.synchronize()
                 v = 0
                 while True:
                     if vlist is not None:
