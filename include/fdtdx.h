@@ -152,9 +152,9 @@ int fdtdx_propagate_ptr(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
  * from `mid` (the cube a single step from `in` would have written), those of the skipped even
  * level from `in`.  `out` must already hold the shell of its level: that of `in` for nsteps = 2
  * (out != mid), that of `mid` for nsteps = 3 (out may be `mid` itself: the launch reads only its
- * shell cells and writes only interior cells).  Radius-1 programs in device order only
- * (FDTDX_ERR_UNSUPPORTED otherwise).  Towards a neighbouring slab the range needs nsteps ghost
- * planes (create the context with M >= nsteps). */
+ * shell cells and writes only interior cells).  Device order only; radius-1 programs (star, jacobi)
+ * with nsteps 2 or 3, the radius-2 star with nsteps 2 (FDTDX_ERR_UNSUPPORTED otherwise).  Towards a
+ * neighbouring slab the range needs nsteps x radius ghost planes (create the context with M that large). */
 int fdtdx_propagate_fused_planes(fdtdx_ctx *ctx, const char *out, const char *in, const char *mid,
                                  const fdtdx_program *prog, uint32_t nsteps, uint64_t z_lo, uint64_t z_hi,
                                  void *stream);
