@@ -26,7 +26,7 @@ for spec in sys.argv[2:]:
     for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
         shutil.copy(f, base + "_kernel_stats.csv")
     traffic[f"{variant}_n512"] = {
-        "kernel": summ.get("kernel"), "avg_us": summ.get("avg_us"),
+        "kernel": summ.get("kernel"), "avg_us": summ.get("avg_us"), "timed_avg_us": summ.get("timed_avg_us"),
         "hbm_bytes_per_launch": summ.get("hbm_bytes_per_launch"),
         "read_bytes_corrected": summ.get("read_bytes_corrected"), "write_bytes": summ.get("write_bytes"),
         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, units of 1024 B; FETCH_SIZE doubled "
