@@ -138,7 +138,11 @@ class SlabRunner:
 
     def _exchange_ops(self, name):
         """P2P ops moving this cube's boundary planes into the neighbours' ghost planes
-        (commCubeHalo, stencil.h:639-647)."""
+        (commCubeHalo, stencil.h:639-647).  Built once per cube: the plane views never change, and
+        rebuilding them costs 10 us of the ~100 us the host spends per exchange."""
+        cache = self.__dict__.setdefault("_ops", {})
+        if name in cache:
+            return cache[name]
         M, ops = self.M, []
         if self.has_lo:
             ops.append(dist.P2POp(dist.isend, self.b.planes(name, M, M), self.rank - 1, self.group))
@@ -146,6 +150,7 @@ class SlabRunner:
         if self.has_hi:
             ops.append(dist.P2POp(dist.isend, self.b.planes(name, self.local - 2 * M, M), self.rank + 1, self.group))
             ops.append(dist.P2POp(dist.irecv, self.b.planes(name, self.local - M, M), self.rank + 1, self.group))
+        cache[name] = ops
         return ops
 
     def _start_exchange(self, name):
