@@ -580,35 +580,63 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
     const int owned = v->nw * v->ry - 2 * reach;
     p.gy = (p.ny - 2 * v->radius + owned - 1) / owned;
     const int nq = (p.nx + 3) / 4, tq = 64 * v->rx;
-    if (nq <= tq)
-        p.gx = 1, p.qstep = tq, p.qbase = 0;
-    else
-        p.qstep = tq - 2, p.qbase = -1, p.gx = (nq + p.qstep - 1) / p.qstep;
-    const long long nz = p.z_hi - p.z_lo;
-    long long chunks = ctx->opt_tb_zchunks;
-    if (chunks <= 0) {
-        // The fused kernel runs one workgroup per CU (registers, LDS), so N workgroups take
-        // ceil(N/256) rounds of the 256 CUs, and every chunk pays for filling its queues (kt planes
-        // re-read, plus start-up: about 6 planes' worth in all, from timings at 512^3 and 1024^3):
-        // take the chunk count with the best product of the two efficiencies.
-        const long long tiles = (long long)p.gx * p.gy;
-        double best = -1.0;
-        chunks = 1;
-        for (long long cnt = 1; cnt <= std::max<long long>(1, nz / 16) && cnt * tiles <= 4096; cnt++) {
-            const long long len = (nz + cnt - 1) / cnt, n = tiles * ((nz + len - 1) / len);
-            const double eff = (double)n / (double)((n + 255) / 256 * 256) * (double)len / (double)(len + 4 + reach);
-            if (eff > best + 1e-9) best = eff, chunks = cnt;
-        }
+    // Rows wider than one tile are cut into x tiles that overlap by one quad on each side (a tile stores
+    // tq-2 quads).  Where the last tile has at most 62 quads left to store and the shape exists at half
+    // the width, that tile is launched separately with the half-width kernel: rows of 1024 cells then
+    // cost 2.5 tile widths instead of 3.
+    const TbVariantInfo *narrow = nullptr;
+    int gx_full = 1;
+    if (nq <= tq) {
+        p.gx = 1, p.qstep = tq, p.qbase = 0, p.xt = 0;
+    } else {
+        p.qstep = tq - 2, p.qbase = -1, p.xt = 1;
+        gx_full = (nq + p.qstep - 1) / p.qstep;
+        p.gx = gx_full;
+        const int rem = nq - (gx_full - 1) * p.qstep;
+        if (rem <= 62 && v->rx == 2 && ctx->opt_tb_variant < 0)
+            for (int i = 0; i < num_tb_variants(); i++) {
+                const TbVariantInfo *c = tb_variant(i);
+                if (c->order == v->order && c->kt == v->kt && c->radius == v->radius && c->nw == v->nw && c->ry == v->ry && c->rx == 1) narrow = c;
+            }
+        if (narrow) p.gx = gx_full - 1;
     }
-    chunks = std::max<long long>(1, std::min(chunks, nz));
-    p.zchunk = (int)((nz + chunks - 1) / chunks);
-    p.gz = (int)((nz + p.zchunk - 1) / p.zchunk);
-    if ((long long)p.gx * p.gy * p.gz > 0x7fffffffLL) return fail(FDTDX_ERR_UNSUPPORTED, "grid too large");
-    v->launch(p, dim3((unsigned)(p.gx * p.gy * p.gz)), (hipStream_t)stream);
-    HIP_TRY(hipGetLastError());
+    const long long nz = p.z_hi - p.z_lo;
+    auto launch_part = [&](const TbVariantInfo *k, TbParams q) -> int {
+        long long chunks = ctx->opt_tb_zchunks;
+        if (chunks <= 0) {
+            // The fused kernel runs one workgroup per CU (registers, LDS), so N workgroups take
+            // ceil(N/256) rounds of the 256 CUs, and every chunk pays for filling its queues (the planes a
+            // launch reaches beyond its range are re-read, plus start-up: about 6 planes' worth in all, from
+            // timings at 512^3 and 1024^3): take the chunk count with the best product of the two efficiencies.
+            const long long tiles = (long long)q.gx * q.gy;
+            double best = -1.0;
+            chunks = 1;
+            for (long long cnt = 1; cnt <= std::max<long long>(1, nz / 16) && cnt * tiles <= 4096; cnt++) {
+                const long long len = (nz + cnt - 1) / cnt, n = tiles * ((nz + len - 1) / len);
+                const double eff = (double)n / (double)((n + 255) / 256 * 256) * (double)len / (double)(len + 4 + reach);
+                if (eff > best + 1e-9) best = eff, chunks = cnt;
+            }
+        }
+        chunks = std::max<long long>(1, std::min(chunks, nz));
+        q.zchunk = (int)((nz + chunks - 1) / chunks);
+        q.gz = (int)((nz + q.zchunk - 1) / q.zchunk);
+        if ((long long)q.gx * q.gy * q.gz > 0x7fffffffLL) return fail(FDTDX_ERR_UNSUPPORTED, "grid too large");
+        k->launch(q, dim3((unsigned)(q.gx * q.gy * q.gz)), (hipStream_t)stream);
+        HIP_TRY(hipGetLastError());
+        p.gz = q.gz, p.zchunk = q.zchunk;
+        return FDTDX_OK;
+    };
+    int rc;
+    if (narrow) {  // first the half-width tail (its grid is reported last otherwise), then the full-width tiles
+        TbParams t = p;
+        t.gx = 1, t.qbase = -1 + (gx_full - 1) * p.qstep;
+        if ((rc = launch_part(narrow, t))) return rc;
+    }
+    if ((rc = launch_part(v, p))) return rc;
     ctx->launches++;
-    snprintf(ctx->last_fused, sizeof(ctx->last_fused), "fused%d kind=%u r=%d waves=%d rows/wave=%d quads/lane/row=%d tile_rows=%d(stored %d) threads=%d lds=%d grid=%dx%dx%d zchunk=%d",
-             v->kt, prog->kind, v->radius, v->nw, v->ry, v->rx, v->nw * v->ry, owned, v->threads, v->lds_bytes, p.gx, p.gy, p.gz, p.zchunk);
+    snprintf(ctx->last_fused, sizeof(ctx->last_fused), "fused%d kind=%u r=%d waves=%d rows/wave=%d quads/lane/row=%d tile_rows=%d(stored %d) threads=%d lds=%d grid=%dx%dx%d%s zchunk=%d",
+             v->kt, prog->kind, v->radius, v->nw, v->ry, v->rx, v->nw * v->ry, owned, v->threads, v->lds_bytes, p.gx, p.gy, p.gz,
+             narrow ? "+half-width tail" : "", p.zchunk);
     return FDTDX_OK;
 }
 

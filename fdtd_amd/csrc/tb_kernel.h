@@ -47,6 +47,7 @@ struct TbParams {
     int zchunk;
     int gx, gy, gz;    // x tiles, y tiles, z chunks (1-D launch of gx*gy*gz workgroups)
     int qstep, qbase;  // x tile bx loads quads [qbase + bx*qstep, +64*RX); one tile: qbase 0, else -1 (see kernel)
+    int xt;            // rows are cut into x tiles (possibly launched separately): a tile does not store its two outermost quads
     float c[7];
 };
 
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(NW * 64) void tb_r1_kernel(const TbParams p)
     // side: the outermost quad of a tile only feeds its neighbours' lower-level values (a level-KT
     // cell reaches KT <= 4 cells, i.e. never beyond the adjacent quad) and is stored by the next tile.
     const int tq0 = p.qbase + bx * p.qstep;
-    const bool xtiled = p.gx > 1;
+    const bool xtiled = p.xt != 0;
     const int zs = p.z_lo + bz * p.zchunk;
     const int ze = min(zs + p.zchunk, p.z_hi);
     if (zs >= ze) return;

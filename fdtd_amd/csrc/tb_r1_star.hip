@@ -13,3 +13,4 @@ FDTDX_TB_VARIANT(2, 5, 4, 2, ORD_STAR_CHAIN)
 FDTDX_TB_VARIANT(2, 6, 4, 2, ORD_STAR_CHAIN)
 FDTDX_TB_VARIANT(2, 6, 3, 2, ORD_STAR_CHAIN)
 FDTDX_TB_VARIANT(2, 16, 1, 2, ORD_STAR_CHAIN)
+FDTDX_TB_VARIANT(3, 16, 1, 1, ORD_STAR_CHAIN)  // half-width tile: the last x tile of rows wider than 128 quads

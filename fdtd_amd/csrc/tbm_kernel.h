@@ -99,7 +99,7 @@ __global__ __launch_bounds__(NW * 64) void tb_rm_kernel(const TbParams p)
         logical_tile(g, bx, by, bz);
     }
     const int tq0 = p.qbase + bx * p.qstep;
-    const bool xtiled = p.gx > 1;
+    const bool xtiled = p.xt != 0;
     const int zs = p.z_lo + bz * p.zchunk;
     const int ze = min(zs + p.zchunk, p.z_hi);
     if (zs >= ze) return;

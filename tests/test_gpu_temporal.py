@@ -50,7 +50,7 @@ def test_auto_fuses_three_steps(oracle_cpu):
     assert "fused3" in run(oracle_cpu, "star", (13, 61, 509), 10)
 
 
-@pytest.mark.parametrize("kt,variant", [(2, v) for v in range(9)] + [(3, 0), (3, 1)])
+@pytest.mark.parametrize("kt,variant", [(2, v) for v in range(9)] + [(3, 0), (3, 1), (3, 2)])
 @pytest.mark.parametrize("kind", ["star", "jacobi7"])
 def test_every_fused_shape(oracle_cpu, kind, kt, variant):
     info = run(oracle_cpu, kind, (21, 75, 512), 7, tb_variant=variant, tb_zchunks=3, temporal=kt)
