@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--variant", default="jacobi", choices=sorted(VARIANTS))
     ap.add_argument("--size", dest="n", type=int, default=512, help="slab edge: every GPU owns n planes of n x n cells")
+    ap.add_argument("--grid", default="",
+                    help="Z,Y,X of a fixed global grid cut into z-slabs over the ranks (strong scaling, e.g. 2048,1024,1024); "
+                         "sweep variants only; default: weak scaling with --size")
     ap.add_argument("--temporal", type=int, default=1,
                     help="time steps fused per launch where a fused kernel exists: 1 = deepest (default), 2, 3, 0 = none")
     ap.add_argument("--spinup-ms", type=float, default=100.0,
@@ -266,7 +269,8 @@ def main():
         ghost = radius
         if world > 1 and kind in ("star", "jacobi7") and radius <= 2 and a.temporal != 0:
             ghost = 3 if radius == 1 else 4
-        be = HipSlabBackend(n * world, n, n, ghost, rank, world, local_rank)
+        Zg, Yg, Xg = ([int(v) for v in a.grid.split(",")] if a.grid else [n * world, n, n])
+        be = HipSlabBackend(Zg, Yg, Xg, ghost, rank, world, local_rank)
         be.alloc("p0")
         be.alloc("p1")
         if kind == "jacobi7":
@@ -307,8 +311,8 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        cells_rank = float(run.z_hi - run.z_lo) * float(n - 2 * radius) ** 2   # this rank, one step
-        cells_all = (float(n * world - 2 * radius)) * float(n - 2 * radius) ** 2
+        cells_rank = float(run.z_hi - run.z_lo) * float(Yg - 2 * radius) * float(Xg - 2 * radius)   # this rank, one step
+        cells_all = float(Zg - 2 * radius) * float(Yg - 2 * radius) * float(Xg - 2 * radius)
         info = be.st.lastLaunchInfo()
         nl_ = launches() - l0
         be.st.close()
@@ -337,22 +341,26 @@ def main():
         try:
             key = a.variant + ("_singlestep" if a.temporal == 0 and VARIANTS[a.variant][1] == 1 and a.variant != "fdtdspc" else "")
             if world == 1:  # the profiled figure is per whole-slab launch; split launches on several ranks differ
-                traffic = json.load(open(tf)).get(f"{key}_n{a.n}", {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tf)).get(f"{key}_n{a.n}", {}).get("hbm_bytes_per_launch") if not a.grid else None
         except Exception:
             traffic = None
 
     grid = [a.n, a.n] if r["kind"] == "yee2d" else [a.n * world, a.n, a.n]
+    fixed = bool(a.grid) and r["kind"] in ("star", "spc13", "jacobi7")
+    if fixed:
+        grid = [int(v) for v in a.grid.split(",")]
     if r["kind"] == "yee3d":
         workload = f"yee3d (extension): six-field E/H step = H half step + E half step, {a.n}^3 fp32 grid, {a.steps} steps"
     elif r["kind"] == "yee2d":
         workload = f"yee2d (extension): ex/ey/hz step on a {a.n}x{a.n} fp32 grid, {a.steps} steps"
     else:
         workload = (f"{a.variant}: {VARIANTS[a.variant][0]} radius {r['radius']} sweep ({VARIANTS[a.variant][2]}), "
-                    f"{a.n * world}x{a.n}x{a.n} fp32 grid, {a.steps} steps, z-slabs of {a.n} planes per GPU")
+                    f"{grid[0]}x{grid[1]}x{grid[2]} fp32 grid, {a.steps} steps, "
+                    + (f"cut into {world} z-slabs" if fixed else f"z-slabs of {a.n} planes per GPU"))
     line = {
         "metric": "cell-updates/sec", "value": round(value, 2), "unit": "Gcell/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(r["dt"] / a.steps * 1e3, 5),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if fixed else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "grid": grid, "radius": r["radius"], "parallelism": f"zslab{world}", "kernel": r["info"],
                    "spinup_ms": a.spinup_ms},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
