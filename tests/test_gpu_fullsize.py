@@ -34,7 +34,10 @@ def gpu_run(kind, M, a, b, steps):
     return ga, gb
 
 
-@pytest.mark.parametrize("kind,M,steps", [("star", 1, 3), ("star", 4, 2), ("star", 8, 2), ("spc13", 1, 2), ("jacobi7", 1, 3)])
+@pytest.mark.parametrize("kind,M,steps", [("star", 1, 3), ("star", 4, 2), ("star", 8, 2), ("spc13", 1, 2), ("jacobi7", 1, 3),
+                                           # four steps and more run through the fused kernels (three steps per launch at
+                                           # radius 1, two at radius 2) and finish with single steps
+                                           ("star", 1, 7), ("jacobi7", 1, 8), ("star", 2, 6)])
 def test_fullsize_vs_oracle(oracle_cpu, kind, M, steps):
     if kind == "jacobi7":
         a = oracle_cpu.init_jacobi(N, N, N)
