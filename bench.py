@@ -40,7 +40,7 @@ VARIANTS = {  # name -> (program kind, radius, reference driver)
     "jacobi": ("jacobi7", 1, "jacobi.cu"),
     "main": ("composite", 4, "main.cu"),  # sweep + inject + filt + mul (main.cu:149-171), one rank
     # extensions without a counterpart in the reference (defined by oracle/fdtd_oracle.c):
-    "yee3d": ("yee3d", 1, "none: extension"),  # six-field E/H step, 72 B per cell-step as two half steps
+    "yee3d": ("yee3d", 1, "none: extension"),  # six-field E/H step, 48 B per cell-step fused (72 as two half steps)
     "yee2d": ("yee2d", 1, "none: extension"),  # ex/ey/hz on n x n, 36 B per cell-step as two launches (--size 2048)
 }
 BYTES_PER_UPDATE_MAIN = 24.0  # p1, vel, old p0, sum read + p0, sum write
@@ -230,9 +230,23 @@ def main():
                                         generator=torch.Generator(device=dev).manual_seed(i))
                 st.attachCube(name, bufs[name].data_ptr(), bufs[name].numel() * 4)
             cs = torch.cuda.current_stream().cuda_stream
-            loop = lambda k: [st.yee3dStep(names, 0.31, 0.27, stream=cs) for _ in range(k)]
+            if a.temporal:  # one launch per step, out of place between two sets of six cubes (48 B per cell)
+                names_b = tuple(n_ + "_b" for n_ in names)
+                for n_, nb in zip(names, names_b):
+                    bufs[nb] = bufs[n_].clone()
+                    st.attachCube(nb, bufs[nb].data_ptr(), bufs[nb].numel() * 4)
+                sets, done = (names, names_b), [0]
+
+                def loop(k):
+                    for _ in range(k):
+                        t = done[0]
+                        st.yee3dStepFused(sets[t % 2], sets[(t + 1) % 2], 0.31, 0.27, stream=cs)
+                        done[0] = t + 1
+                info = "yee3d_fused_kernel, one launch per step (H half + E half, out of place)"
+            else:
+                loop = lambda k: [st.yee3dStep(names, 0.31, 0.27, stream=cs) for _ in range(k)]
+                info = "yee3d_half_kernel x2 per step (H half, E half)"
             cells = float(n - 2) ** 3
-            info = "yee3d_half_kernel x2 per step (H half, E half)"
             fields = list(bufs.values())
         else:
             ex, ey, hz = (torch.rand(n * n, dtype=torch.float32, device=dev) for _ in range(3))
@@ -251,7 +265,8 @@ def main():
         e1.record()
         barrier()
         dt = time.perf_counter() - t0
-        return dict(dt=dt, ev_ms=e0.elapsed_time(e1), cells_rank=cells, cells_all=cells, info=info, kind=kind, radius=1, launches=2 * steps)
+        nl = steps if (kind == "yee3d" and a.temporal) else 2 * steps
+        return dict(dt=dt, ev_ms=e0.elapsed_time(e1), cells_rank=cells, cells_all=cells, info=info, kind=kind, radius=1, launches=nl)
 
     def time_variant(name, steps, warmup):
         kind, radius, _ = VARIANTS[name]
@@ -332,8 +347,8 @@ def main():
     nlaunch = r["launches"] or a.steps
     steps_per_launch = a.steps / nlaunch
     launch_s = r["ev_ms"] * 1e-3 / nlaunch
-    # bytes per cell-step: main 24 (one fused step); yee3d 72 and yee2d 36 per step of two launches
-    bpu = {"composite": BYTES_PER_UPDATE_MAIN, "yee3d": 72.0, "yee2d": 36.0}.get(r["kind"], BYTES_PER_UPDATE)
+    # bytes per cell-step: main 24 (one fused step); yee3d 48 in one launch (72 as two half steps), yee2d 36 as two launches
+    bpu = {"composite": BYTES_PER_UPDATE_MAIN, "yee3d": 48.0 if a.temporal else 72.0, "yee2d": 36.0}.get(r["kind"], BYTES_PER_UPDATE)
     achieved = bpu * r["cells_rank"] * steps_per_launch / launch_s * 1e-9
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
@@ -350,7 +365,8 @@ def main():
     if fixed:
         grid = [int(v) for v in a.grid.split(",")]
     if r["kind"] == "yee3d":
-        workload = f"yee3d (extension): six-field E/H step = H half step + E half step, {a.n}^3 fp32 grid, {a.steps} steps"
+        workload = (f"yee3d (extension): six-field E/H step = H half step + E half step "
+                    f"({'one fused launch' if a.temporal else 'two launches'}), {a.n}^3 fp32 grid, {a.steps} steps")
     elif r["kind"] == "yee2d":
         workload = f"yee2d (extension): ex/ey/hz step on a {a.n}x{a.n} fp32 grid, {a.steps} steps"
     else:

@@ -1061,6 +1061,45 @@ extern "C" int fdtdx_yee3d_step(fdtdx_ctx *ctx, const char *const fields[6], flo
     return fdtdx_yee3d_half(ctx, fields, 1, ce, order, 1, hi, stream);
 }
 
+extern "C" int fdtdx_yee3d_step_fused(fdtdx_ctx *ctx, const char *const before[6], const char *const after[6], float ce, float ch,
+                                      uint32_t order, void *stream)
+{
+    if (!ctx || !before || !after) return fail(FDTDX_ERR_INVALID, "null argument");
+    if (ctx->cfg.nprocs != 1) return fail(FDTDX_ERR_UNSUPPORTED, "fdtdx_yee3d_step_fused runs on one rank");
+    if (order != FDTDX_ORDER_CHAIN && order != FDTDX_ORDER_GOLDEN) return fail(FDTDX_ERR_INVALID, "unknown order %u", order);
+    const fdtdx_geometry &g = ctx->g;
+    YeeFusedParams p;
+    float *f[12];
+    int rc;
+    for (int i = 0; i < 12; i++) {
+        if ((rc = find_cube(ctx, i < 6 ? before[i] : after[i - 6], &f[i]))) return rc;
+        for (int k = 0; k < i; k++)
+            if (f[k] == f[i]) return fail(FDTDX_ERR_INVALID, "the fused step needs twelve different cubes (six before, six after)");
+    }
+    for (int i = 0; i < 3; i++) p.eo[i] = f[i], p.ho[i] = f[3 + i], p.en[i] = f[6 + i], p.hn[i] = f[9 + i];
+    p.plane = (long long)g.plane, p.px = (int)g.pitch_x, p.nx = (int)ctx->cfg.X, p.ny = (int)ctx->cfg.Y, p.nz = (int)g.local_planes;
+    p.z_lo = 1, p.z_hi = (int)g.local_planes - 1, p.ce = ce, p.ch = ch;
+#ifndef YEE_LY
+#define YEE_LY 7
+#endif
+    constexpr int LY = YEE_LY;
+    const unsigned gx = (unsigned)(((ctx->cfg.X + 3) / 4 + 63) / 64), gy = (unsigned)((ctx->cfg.Y - 2 + LY - 1) / LY);
+    const long long nz = p.z_hi - p.z_lo;
+    // every chunk recomputes the H plane below it: chunks of at least 32 planes keep that under 3 %
+    long long chunks = std::max<long long>(1, std::min<long long>(nz / 32, 4096 / std::max<long long>(1, (long long)gx * gy)));
+    p.zchunk = (int)((nz + chunks - 1) / chunks);
+    const unsigned gz = (unsigned)((nz + p.zchunk - 1) / p.zchunk);
+    if ((long long)gx * gy * gz > 0x7fffffffLL) return fail(FDTDX_ERR_UNSUPPORTED, "grid too large");
+    p.gx = (int)gx, p.gy = (int)gy, p.gz = (int)gz;
+    const dim3 grid(gx * gy * gz), block(64 * (LY + 1));
+    if (order == FDTDX_ORDER_GOLDEN)
+        hipLaunchKernelGGL((yee3d_fused_kernel<LY, 1>), grid, block, 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((yee3d_fused_kernel<LY, 0>), grid, block, 0, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return FDTDX_OK;
+}
+
 extern "C" int fdtdx_yee2d_steps(int device, float *ex, float *ey, float *hz, uint64_t nx, uint64_t ny, int t0, int steps, float ce, float ch,
                                  uint32_t order, void *stream)
 {

@@ -36,6 +36,11 @@ __device__ __forceinline__ void st4_stream(float *p, const float (&v)[4])
     __builtin_nontemporal_store(f, reinterpret_cast<f32x4 *>(p));
 }
 
+__device__ __forceinline__ float dpp_prev_lane(float v)  // lane l receives lane l-1 (lane 0: lane 63)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xF, 0xF, false));
+}
+
 __device__ __forceinline__ float upd(float a, float c, float d, int golden) { return golden ? a + c * d : __builtin_fmaf(c, d, a); }
 
 // WHICH = 0: H -= ch*curl(E) with forward differences; WHICH = 1: E += ce*curl(H) with backward differences.
@@ -104,6 +109,162 @@ __global__ __launch_bounds__(256) void yee3d_half_kernel(const YeeParams p)
         } else {
             A0 = Az, B0 = Bz;  // z+1 becomes the current plane
         }
+    }
+}
+
+// ---- one launch for the whole step: H half step and E half step fused, out of place -----------------
+// The two half steps of one time step read and write every field twice (72 bytes per cell).  Fused, a
+// thread that has just made H at (z, y, x) needs the new H at z-1 (its own previous plane: registers),
+// at y-1 (the thread row below: LDS, one extra halo row of threads per tile recomputes it at the tile
+// edge) and at x-1 (the neighbouring lane: DPP; lane 0 recomputes that one cell) to finish E at the
+// same cell: every field is read once and written once, 48 bytes per cell.  That cannot be done in
+// place (a neighbouring tile would find fields half updated), so the step goes from six cubes into six
+// others, which must already carry the shell (the step never changes it).  Same arithmetic, operand
+// for operand, as the two half-step kernels above.
+struct YeeFusedParams {
+    const float *eo[3], *ho[3];  // Ex, Ey, Ez / Hx, Hy, Hz before the step
+    float *en[3], *hn[3];        // after the step
+    long long plane;
+    int px, nx, ny, nz;
+    int z_lo, z_hi, zchunk;
+    int gx, gy, gz;  // x tiles, y tiles, z chunks (1-D launch of gx*gy*gz workgroups, dealt to the XCDs in runs)
+    float ce, ch;
+};
+
+template <int LY, int GOLDEN>
+__global__ __launch_bounds__(64 * (LY + 1)) void yee3d_fused_kernel(const YeeFusedParams p)
+{
+    __shared__ float4 sx[2][LY + 1][64], sz[2][LY + 1][64];  // new Hx, Hz of the current plane, one row per wave
+    const int lane = threadIdx.x & 63;
+    const int ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0: the row below the tile (H only)
+    int bx, by, bz;
+    {
+        SweepParams g;  // only the grid fields are read by logical_tile
+        g.gx = p.gx, g.gy = p.gy, g.gz = p.gz;
+        logical_tile(g, bx, by, bz);  // neighbouring tiles share an L2: the halo row is a neighbour's own row
+    }
+    const int x0 = 4 * (bx * 64 + lane);
+    const int y = by * LY + ty;  // the tile stores rows 1 + by*LY .. by*LY + LY
+    const int zs = p.z_lo + bz * p.zchunk, ze = min(zs + p.zchunk, p.z_hi);
+    if (zs >= ze) return;  // the whole workgroup
+    const bool dom = (y < p.ny) && (x0 < p.nx);
+    const bool yin = (y >= 1) && (y < p.ny - 1);
+    bool m[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) m[i] = dom && yin && (x0 + i >= 1) && (x0 + i < p.nx - 1);
+    const bool stores = (ty >= 1) && (m[0] || m[1] || m[2] || m[3]);
+    const bool left = dom && (ty >= 1) && (lane == 0) && (x0 >= 4);  // this lane recomputes H at cell x0-1
+    const float nch = -p.ch;
+    const long long row = (long long)y * p.px + x0;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto ld = [&](const float *f, long long a) { return dom ? ld4(f + a) : zero; };
+    auto lds_ = [&](const float *f, long long a) { return dom ? ld4_stream(f + a) : zero; };
+    const bool upok = dom && (y + 1 < p.ny);  // row y+1 exists (beyond the last row of the last plane the cube ends)
+    auto ldu = [&](const float *f, long long a) { return upok ? ld4(f + a + p.px) : zero; };
+
+    // Everything plane z contributes from memory.  Whatever is needed of E at plane z+1 is fetched now, while the
+    // neighbouring lanes and rows fetch the same lines as their own data, and carried in registers to the next
+    // plane: a line asked for again one plane later has left the L2 by then.
+    struct In {
+        float4 ez, ex1, ey1;   // Ez at z; Ex, Ey at z+1 (they become the next plane's own Ex, Ey)
+        float4 h[3];           // H before the step
+        float4 ezu, exu1;      // row y+1: Ez at z, Ex at z+1
+        float ezr, eyr1;       // the cell right of the quad: Ez at z, Ey at z+1
+        float lhy, lhz, lez, lex1, lexu1, ley1;  // lane 0 only, cell x0-1: Hy, Hz, Ez at z; Ex, Ex of row y+1, Ey at z+1
+    };
+    struct Carry {
+        float4 ex, ey, exu;    // own Ex, Ey and Ex of row y+1 at the current plane
+        float eyr, lex, lexu, ley;
+    };
+    const bool more = dom && (x0 + 4 < p.nx);
+    auto fetch = [&](int z, In &v) {
+        const long long a = (long long)z * p.plane + row, a1 = a + p.plane;
+        v.ez = ld(p.eo[2], a);
+        v.ex1 = ld(p.eo[0], a1), v.ey1 = ld(p.eo[1], a1);
+        v.h[0] = lds_(p.ho[0], a), v.h[1] = lds_(p.ho[1], a), v.h[2] = lds_(p.ho[2], a);  // read once: streamed
+        v.ezu = ldu(p.eo[2], a), v.exu1 = ldu(p.eo[0], a1);
+        v.ezr = more ? p.eo[2][a + 4] : 0.f, v.eyr1 = more ? p.eo[1][a1 + 4] : 0.f;
+        if (left) {
+            const long long b = a - 1, b1 = a1 - 1;
+            v.lhy = p.ho[1][b], v.lhz = p.ho[2][b], v.lez = p.eo[2][b];
+            v.lex1 = p.eo[0][b1], v.lexu1 = upok ? p.eo[0][b1 + p.px] : 0.f, v.ley1 = p.eo[1][b1];
+        }
+    };
+    auto advance = [&](Carry &c, const In &v) {
+        c.ex = v.ex1, c.ey = v.ey1, c.exu = v.exu1, c.eyr = v.eyr1, c.lex = v.lex1, c.lexu = v.lexu1, c.ley = v.ley1;
+    };
+    // H after the step at plane z for this thread's quad
+    auto h_plane = [&](int z, const In &v, const Carry &c, float4 (&h)[3]) {
+        h[0] = v.h[0], h[1] = v.h[1], h[2] = v.h[2];
+        const bool zin = (z >= 1) && (z < p.nz - 1);
+        if (!zin) return;  // uniform: a shell plane keeps its H
+        const float ex0[4] = {c.ex.x, c.ex.y, c.ex.z, c.ex.w}, ey0[4] = {c.ey.x, c.ey.y, c.ey.z, c.ey.w};
+        const float ez0[4] = {v.ez.x, v.ez.y, v.ez.z, v.ez.w};
+        const float exz[4] = {v.ex1.x, v.ex1.y, v.ex1.z, v.ex1.w}, eyz[4] = {v.ey1.x, v.ey1.y, v.ey1.z, v.ey1.w};
+        const float ezy[4] = {v.ezu.x, v.ezu.y, v.ezu.z, v.ezu.w}, exy[4] = {c.exu.x, c.exu.y, c.exu.z, c.exu.w};
+        const float ezx[4] = {ez0[1], ez0[2], ez0[3], v.ezr}, eyx[4] = {ey0[1], ey0[2], ey0[3], c.eyr};
+        float hx[4] = {h[0].x, h[0].y, h[0].z, h[0].w}, hy[4] = {h[1].x, h[1].y, h[1].z, h[1].w}, hz[4] = {h[2].x, h[2].y, h[2].z, h[2].w};
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (m[i]) {
+                hx[i] = upd(hx[i], nch, (ezy[i] - ez0[i]) - (eyz[i] - ey0[i]), GOLDEN);
+                hy[i] = upd(hy[i], nch, (exz[i] - ex0[i]) - (ezx[i] - ez0[i]), GOLDEN);
+                hz[i] = upd(hz[i], nch, (eyx[i] - ey0[i]) - (exy[i] - ex0[i]), GOLDEN);
+            }
+        h[0] = make_float4(hx[0], hx[1], hx[2], hx[3]), h[1] = make_float4(hy[0], hy[1], hy[2], hy[3]);
+        h[2] = make_float4(hz[0], hz[1], hz[2], hz[3]);
+    };
+
+    In cur;
+    Carry c;
+    float4 hprev[3], h[3];
+    {   // H after the step at plane zs-1; what the loop carries is loaded directly for that one plane
+        const long long a = (long long)(zs - 1) * p.plane + row;
+        c.ex = ld(p.eo[0], a), c.ey = ld(p.eo[1], a), c.exu = ldu(p.eo[0], a);
+        c.eyr = more ? p.eo[1][a + 4] : 0.f;
+        c.lex = c.lexu = c.ley = 0.f;
+        if (left) c.lex = p.eo[0][a - 1], c.lexu = upok ? p.eo[0][a - 1 + p.px] : 0.f, c.ley = p.eo[1][a - 1];
+        fetch(zs - 1, cur);
+        h_plane(zs - 1, cur, c, hprev);
+        advance(c, cur);
+    }
+    int par = 0;
+    for (int z = zs; z < ze; z++, par ^= 1) {
+        const long long a = (long long)z * p.plane + row;
+        fetch(z, cur);  // (fetching a whole plane ahead into a second register set was measured: no faster, fewer waves fit)
+        h_plane(z, cur, c, h);
+        sx[par][ty][lane] = h[0], sz[par][ty][lane] = h[2];
+        // new Hy, Hz at the cell left of the quad: the neighbouring lane has them, lane 0 works them out
+        float hyl = dpp_prev_lane(h[1].w), hzl = dpp_prev_lane(h[2].w);
+        if (left) {
+            hyl = cur.lhy, hzl = cur.lhz;
+            if (yin) {
+                hyl = upd(hyl, nch, (cur.lex1 - c.lex) - (cur.ez.x - cur.lez), GOLDEN);
+                hzl = upd(hzl, nch, (c.ey.x - c.ley) - (c.lexu - c.lex), GOLDEN);
+            }
+        }
+        __syncthreads();
+        if (ty >= 1) {  // uniform per wave
+            const float4 hxd = sx[par][ty - 1][lane], hzd = sz[par][ty - 1][lane];
+            const float hx[4] = {h[0].x, h[0].y, h[0].z, h[0].w}, hy[4] = {h[1].x, h[1].y, h[1].z, h[1].w}, hz[4] = {h[2].x, h[2].y, h[2].z, h[2].w};
+            const float hxy[4] = {hxd.x, hxd.y, hxd.z, hxd.w}, hzy[4] = {hzd.x, hzd.y, hzd.z, hzd.w};
+            const float hxz[4] = {hprev[0].x, hprev[0].y, hprev[0].z, hprev[0].w}, hyz[4] = {hprev[1].x, hprev[1].y, hprev[1].z, hprev[1].w};
+            const float hyx[4] = {hyl, hy[0], hy[1], hy[2]}, hzx[4] = {hzl, hz[0], hz[1], hz[2]};
+            float ex[4] = {c.ex.x, c.ex.y, c.ex.z, c.ex.w}, ey[4] = {c.ey.x, c.ey.y, c.ey.z, c.ey.w}, ez[4] = {cur.ez.x, cur.ez.y, cur.ez.z, cur.ez.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (m[i]) {
+                    ex[i] = upd(ex[i], p.ce, (hz[i] - hzy[i]) - (hy[i] - hyz[i]), GOLDEN);
+                    ey[i] = upd(ey[i], p.ce, (hx[i] - hxz[i]) - (hz[i] - hzx[i]), GOLDEN);
+                    ez[i] = upd(ez[i], p.ce, (hy[i] - hyx[i]) - (hx[i] - hxy[i]), GOLDEN);
+                }
+            if (stores) {
+                st4_stream(p.hn[0] + a, hx), st4_stream(p.hn[1] + a, hy), st4_stream(p.hn[2] + a, hz);
+                st4_stream(p.en[0] + a, ex), st4_stream(p.en[1] + a, ey), st4_stream(p.en[2] + a, ez);
+            }
+        }
+        hprev[0] = h[0], hprev[1] = h[1];
+        advance(c, cur);
     }
 }
 

@@ -92,6 +92,7 @@ SYMBOLS = {
     "fdtdx_mul_acc": (ctypes.c_int, [_vp, _c, _c, _c, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64, _vp]),
     "fdtdx_yee3d_half": (ctypes.c_int, [_vp, _P(_c), ctypes.c_int, ctypes.c_float, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64, _vp]),
     "fdtdx_yee3d_step": (ctypes.c_int, [_vp, _P(_c), ctypes.c_float, ctypes.c_float, ctypes.c_uint32, _vp]),
+    "fdtdx_yee3d_step_fused": (ctypes.c_int, [_vp, _P(_c), _P(_c), ctypes.c_float, ctypes.c_float, ctypes.c_uint32, _vp]),
     "fdtdx_yee2d_steps": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_float, ctypes.c_float, ctypes.c_uint32, _vp]),
     "fdtdx_halo_region": (ctypes.c_int, [_vp, _c, ctypes.c_int, ctypes.c_int, _P(_vp), _P(ctypes.c_size_t)]),

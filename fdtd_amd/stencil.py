@@ -199,6 +199,12 @@ class Stencil:
     def yee3dStep(self, fields, ce, ch, order=_lib.ORDER_CHAIN, stream=None):
         _lib.check(self._L.fdtdx_yee3d_step(self._h, self._names(fields), ce, ch, order, ctypes.c_void_p(stream or 0)))
 
+    def yee3dStepFused(self, before, after, ce, ch, order=_lib.ORDER_CHAIN, stream=None):
+        """One launch for the whole step, from the six cubes `before` into the six cubes `after` (which must
+        already hold the shell); equal to yee3dStep bit for bit."""
+        _lib.check(self._L.fdtdx_yee3d_step_fused(self._h, self._names(before), self._names(after), ce, ch, order,
+                                                   ctypes.c_void_p(stream or 0)))
+
     # -- halo regions: stencil.h:639-647 --------------------------------------------------
     def haloRegion(self, name, side, what):
         """(device pointer, float count) of the planes to send (what=0) / receive (what=1)

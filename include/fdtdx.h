@@ -238,6 +238,12 @@ int fdtdx_composite_step(fdtdx_ctx *ctx, const char *out, const char *in, const 
 int fdtdx_yee3d_half(fdtdx_ctx *ctx, const char *const fields[6], int which, float coef, uint32_t order, uint64_t z_lo,
                      uint64_t z_hi, void *stream);
 int fdtdx_yee3d_step(fdtdx_ctx *ctx, const char *const fields[6], float ce, float ch, uint32_t order, void *stream);
+/* The same time step in ONE launch, out of place: reads the six cubes `before` (Ex, Ey, Ez, Hx, Hy, Hz), writes the
+ * six cubes `after`; every field crosses HBM once in each direction (48 instead of 72 bytes per cell).  The step never
+ * changes the shell, so the `after` cubes must already hold it (e.g. start them as copies of `before`); a time loop
+ * ping-pongs between the two sets.  Results equal fdtdx_yee3d_step bit for bit.  Extension like the half steps. */
+int fdtdx_yee3d_step_fused(fdtdx_ctx *ctx, const char *const before[6], const char *const after[6], float ce, float ch,
+                           uint32_t order, void *stream);
 /* 2-D ex/ey/hz on dense [nx][ny] device arrays (ny fastest), `steps` steps numbered t0, t0+1, ...:
  *   ey[0][j] = t;  ey[i][j] -= ce*(hz[i][j]-hz[i-1][j]) (i>=1);  ex[i][j] -= ce*(hz[i][j]-hz[i][j-1]) (j>=1);
  *   hz[i][j] -= ch*(((ex[i][j+1]-ex[i][j]) + ey[i+1][j]) - ey[i][j])  (i<nx-1, j<ny-1). */

@@ -35,6 +35,49 @@ def gpu_yee3d(shape, f, steps, order, ce=0.31, ch=0.27):
     return out
 
 
+def gpu_yee3d_fused(shape, f, steps, order, ce=0.31, ch=0.27):
+    """The one-launch step, ping-ponging between two sets of six cubes (both start as the initial fields,
+    so both carry the shell)."""
+    Z, Y, X = shape
+    sets = (NAMES, tuple(n + "_b" for n in NAMES))
+    with Stencil(Z, Y, X, 1) as st:
+        for names in sets:
+            for n, a in zip(names, f):
+                st.mallocCube(n)
+                st.transferCubeToGPU(n, a)
+        for t in range(steps):
+            st.yee3dStepFused(sets[t % 2], sets[(t + 1) % 2], ce, ch, order)
+        st.sync()
+        out = [np.empty(shape, np.float32) for _ in range(6)]
+        for n, a in zip(sets[steps % 2], out):
+            st.transferCubeToCPU(a, n)
+    return out
+
+
+@pytest.mark.parametrize("order", [ORDER_CHAIN, ORDER_GOLDEN])
+@pytest.mark.parametrize("shape", [(3, 3, 3), (9, 14, 21), (20, 37, 260), (40, 9, 513), (70, 23, 1030)])
+def test_yee3d_fused_step_equals_two_half_steps(oracle_cpu, shape, order):
+    """Tiles of 7 rows x 256 cells, z chunks, ragged x: the fused launch equals the CPU definition bit for bit."""
+    f = fields(shape)
+    ref = [a.copy() for a in f]
+    for _ in range(3):
+        oracle_cpu.yee3d_step(ref, 0.31, 0.27, order=ORD[order])
+    got = gpu_yee3d_fused(shape, f, 3, order)
+    for n, g, r in zip(NAMES, got, ref):
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32)), n
+
+
+def test_yee3d_fused_fullsize(oracle_cpu):
+    shape = (256, 256, 256)
+    f = fields(shape, seed=5)
+    ref = [a.copy() for a in f]
+    for _ in range(2):
+        oracle_cpu.yee3d_step(ref, 0.31, 0.27, order=1)
+    got = gpu_yee3d_fused(shape, f, 2, ORDER_CHAIN)
+    for n, g, r in zip(NAMES, got, ref):
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32)), n
+
+
 @pytest.mark.parametrize("order", [ORDER_CHAIN, ORDER_GOLDEN])
 @pytest.mark.parametrize("shape", [(3, 3, 3), (9, 14, 21), (20, 37, 260), (40, 9, 513)])
 def test_yee3d_equals_its_cpu_definition(oracle_cpu, shape, order):
