@@ -155,12 +155,17 @@ __global__ __launch_bounds__(64 * (LY + 1)) void yee3d_fused_kernel(const YeeFus
     const bool stores = (ty >= 1) && (m[0] || m[1] || m[2] || m[3]);
     const bool left = dom && (ty >= 1) && (lane == 0) && (x0 >= 4);  // this lane recomputes H at cell x0-1
     const float nch = -p.ch;
-    const long long row = (long long)y * p.px + x0;
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto ld = [&](const float *f, long long a) { return dom ? ld4(f + a) : zero; };
-    auto lds_ = [&](const float *f, long long a) { return dom ? ld4_stream(f + a) : zero; };
-    const bool upok = dom && (y + 1 < p.ny);  // row y+1 exists (beyond the last row of the last plane the cube ends)
-    auto ldu = [&](const float *f, long long a) { return upok ? ld4(f + a + p.px) : zero; };
+    // Lanes outside the grid read the grid's first quad instead (their results are masked and never stored), a row
+    // y+1 or a cell x+4 that does not exist is replaced by the own row / quad: every load is unconditional, and
+    // nothing is read beyond the cubes.
+    const long long row = dom ? (long long)y * p.px + x0 : 0;
+    const bool upok = dom && (y + 1 < p.ny);
+    const int upo = upok ? p.px : 0;
+    const bool more = dom && (x0 + 4 < p.nx);
+    const int ro = more ? 4 : 0;
+    auto ld = [&](const float *f, long long a) { return ld4(f + a); };
+    auto lds_ = [&](const float *f, long long a) { return ld4_stream(f + a); };
+    auto ldu = [&](const float *f, long long a) { return ld4(f + a + upo); };
 
     // Everything plane z contributes from memory.  Whatever is needed of E at plane z+1 is fetched now, while the
     // neighbouring lanes and rows fetch the same lines as their own data, and carried in registers to the next
@@ -176,18 +181,17 @@ __global__ __launch_bounds__(64 * (LY + 1)) void yee3d_fused_kernel(const YeeFus
         float4 ex, ey, exu;    // own Ex, Ey and Ex of row y+1 at the current plane
         float eyr, lex, lexu, ley;
     };
-    const bool more = dom && (x0 + 4 < p.nx);
     auto fetch = [&](int z, In &v) {
         const long long a = (long long)z * p.plane + row, a1 = a + p.plane;
         v.ez = ld(p.eo[2], a);
         v.ex1 = ld(p.eo[0], a1), v.ey1 = ld(p.eo[1], a1);
         v.h[0] = lds_(p.ho[0], a), v.h[1] = lds_(p.ho[1], a), v.h[2] = lds_(p.ho[2], a);  // read once: streamed
         v.ezu = ldu(p.eo[2], a), v.exu1 = ldu(p.eo[0], a1);
-        v.ezr = more ? p.eo[2][a + 4] : 0.f, v.eyr1 = more ? p.eo[1][a1 + 4] : 0.f;
+        v.ezr = p.eo[2][a + ro], v.eyr1 = p.eo[1][a1 + ro];
         if (left) {
             const long long b = a - 1, b1 = a1 - 1;
             v.lhy = p.ho[1][b], v.lhz = p.ho[2][b], v.lez = p.eo[2][b];
-            v.lex1 = p.eo[0][b1], v.lexu1 = upok ? p.eo[0][b1 + p.px] : 0.f, v.ley1 = p.eo[1][b1];
+            v.lex1 = p.eo[0][b1], v.lexu1 = p.eo[0][b1 + upo], v.ley1 = p.eo[1][b1];
         }
     };
     auto advance = [&](Carry &c, const In &v) {
@@ -205,12 +209,12 @@ __global__ __launch_bounds__(64 * (LY + 1)) void yee3d_fused_kernel(const YeeFus
         const float ezx[4] = {ez0[1], ez0[2], ez0[3], v.ezr}, eyx[4] = {ey0[1], ey0[2], ey0[3], c.eyr};
         float hx[4] = {h[0].x, h[0].y, h[0].z, h[0].w}, hy[4] = {h[1].x, h[1].y, h[1].z, h[1].w}, hz[4] = {h[2].x, h[2].y, h[2].z, h[2].w};
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            if (m[i]) {
-                hx[i] = upd(hx[i], nch, (ezy[i] - ez0[i]) - (eyz[i] - ey0[i]), GOLDEN);
-                hy[i] = upd(hy[i], nch, (exz[i] - ex0[i]) - (ezx[i] - ez0[i]), GOLDEN);
-                hz[i] = upd(hz[i], nch, (eyx[i] - ey0[i]) - (exy[i] - ex0[i]), GOLDEN);
-            }
+        for (int i = 0; i < 4; i++) {  // computed for every cell, kept where the cell is interior (selects, no branches)
+            const float nx_ = upd(hx[i], nch, (ezy[i] - ez0[i]) - (eyz[i] - ey0[i]), GOLDEN);
+            const float ny_ = upd(hy[i], nch, (exz[i] - ex0[i]) - (ezx[i] - ez0[i]), GOLDEN);
+            const float nz_ = upd(hz[i], nch, (eyx[i] - ey0[i]) - (exy[i] - ex0[i]), GOLDEN);
+            hx[i] = m[i] ? nx_ : hx[i], hy[i] = m[i] ? ny_ : hy[i], hz[i] = m[i] ? nz_ : hz[i];
+        }
         h[0] = make_float4(hx[0], hx[1], hx[2], hx[3]), h[1] = make_float4(hy[0], hy[1], hy[2], hy[3]);
         h[2] = make_float4(hz[0], hz[1], hz[2], hz[3]);
     };
@@ -221,9 +225,9 @@ __global__ __launch_bounds__(64 * (LY + 1)) void yee3d_fused_kernel(const YeeFus
     {   // H after the step at plane zs-1; what the loop carries is loaded directly for that one plane
         const long long a = (long long)(zs - 1) * p.plane + row;
         c.ex = ld(p.eo[0], a), c.ey = ld(p.eo[1], a), c.exu = ldu(p.eo[0], a);
-        c.eyr = more ? p.eo[1][a + 4] : 0.f;
+        c.eyr = p.eo[1][a + ro];
         c.lex = c.lexu = c.ley = 0.f;
-        if (left) c.lex = p.eo[0][a - 1], c.lexu = upok ? p.eo[0][a - 1 + p.px] : 0.f, c.ley = p.eo[1][a - 1];
+        if (left) c.lex = p.eo[0][a - 1], c.lexu = p.eo[0][a - 1 + upo], c.ley = p.eo[1][a - 1];
         fetch(zs - 1, cur);
         h_plane(zs - 1, cur, c, hprev);
         advance(c, cur);
@@ -245,19 +249,22 @@ __global__ __launch_bounds__(64 * (LY + 1)) void yee3d_fused_kernel(const YeeFus
         }
         __syncthreads();
         if (ty >= 1) {  // uniform per wave
-            const float4 hxd = sx[par][ty - 1][lane], hzd = sz[par][ty - 1][lane];
+            // whole-quad LDS reads (the single components the compiler would pick, at a 16-byte lane stride, conflict)
+            f32x4 wx = *reinterpret_cast<const f32x4 *>(&sx[par][ty - 1][lane]), wz = *reinterpret_cast<const f32x4 *>(&sz[par][ty - 1][lane]);
+            asm("" : "+v"(wx), "+v"(wz));
+            const float4 hxd = make_float4(wx[0], wx[1], wx[2], wx[3]), hzd = make_float4(wz[0], wz[1], wz[2], wz[3]);
             const float hx[4] = {h[0].x, h[0].y, h[0].z, h[0].w}, hy[4] = {h[1].x, h[1].y, h[1].z, h[1].w}, hz[4] = {h[2].x, h[2].y, h[2].z, h[2].w};
             const float hxy[4] = {hxd.x, hxd.y, hxd.z, hxd.w}, hzy[4] = {hzd.x, hzd.y, hzd.z, hzd.w};
             const float hxz[4] = {hprev[0].x, hprev[0].y, hprev[0].z, hprev[0].w}, hyz[4] = {hprev[1].x, hprev[1].y, hprev[1].z, hprev[1].w};
             const float hyx[4] = {hyl, hy[0], hy[1], hy[2]}, hzx[4] = {hzl, hz[0], hz[1], hz[2]};
             float ex[4] = {c.ex.x, c.ex.y, c.ex.z, c.ex.w}, ey[4] = {c.ey.x, c.ey.y, c.ey.z, c.ey.w}, ez[4] = {cur.ez.x, cur.ez.y, cur.ez.z, cur.ez.w};
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                if (m[i]) {
-                    ex[i] = upd(ex[i], p.ce, (hz[i] - hzy[i]) - (hy[i] - hyz[i]), GOLDEN);
-                    ey[i] = upd(ey[i], p.ce, (hx[i] - hxz[i]) - (hz[i] - hzx[i]), GOLDEN);
-                    ez[i] = upd(ez[i], p.ce, (hy[i] - hyx[i]) - (hx[i] - hxy[i]), GOLDEN);
-                }
+            for (int i = 0; i < 4; i++) {
+                const float nx_ = upd(ex[i], p.ce, (hz[i] - hzy[i]) - (hy[i] - hyz[i]), GOLDEN);
+                const float ny_ = upd(ey[i], p.ce, (hx[i] - hxz[i]) - (hz[i] - hzx[i]), GOLDEN);
+                const float nz_ = upd(ez[i], p.ce, (hy[i] - hyx[i]) - (hx[i] - hxy[i]), GOLDEN);
+                ex[i] = m[i] ? nx_ : ex[i], ey[i] = m[i] ? ny_ : ey[i], ez[i] = m[i] ? nz_ : ez[i];
+            }
             if (stores) {
                 st4_stream(p.hn[0] + a, hx), st4_stream(p.hn[1] + a, hy), st4_stream(p.hn[2] + a, hz);
                 st4_stream(p.en[0] + a, ex), st4_stream(p.en[1] + a, ey), st4_stream(p.en[2] + a, ez);
