@@ -100,7 +100,9 @@ __global__ __launch_bounds__(256) void yee3d_half_kernel(const YeeParams p)
                 dv = (az[i] - a0[i]) - (cx[i] - c0[i]);
                 dw = (bx[i] - b0[i]) - (ay[i] - a0[i]);
             }
-            if (m[i]) u[i] = upd(u[i], c, du, GOLDEN), v[i] = upd(v[i], c, dv, GOLDEN), w[i] = upd(w[i], c, dw, GOLDEN);
+            // computed for every cell, kept where the cell is interior (selects: per-component branches cost more)
+            const float un = upd(u[i], c, du, GOLDEN), vn = upd(v[i], c, dv, GOLDEN), wn = upd(w[i], c, dw, GOLDEN);
+            u[i] = m[i] ? un : u[i], v[i] = m[i] ? vn : v[i], w[i] = m[i] ? wn : w[i];
         }
         st4_stream(U + a, u), st4_stream(V + a, v), st4_stream(W + a, w);
         if (WHICH) {
