@@ -3,6 +3,7 @@
 //   build: hipcc -std=c++17 -O3 --offload-arch=gfx950 -Iinclude examples/functor_driver.hip -Lfdtd_amd -lfdtdx
 //          -Wl,-rpath,$PWD/fdtd_amd -o examples/functor_driver        (fdtd_amd/csrc/Makefile does it)
 //   run:   ./functor_driver        -> one line per case, exit status 0 when every case agrees
+//          ./functor_driver bench  -> throughput of a radius-3 lambda at 512^3 beside the closed program's
 // The lambdas have the signature the reference's drivers use (fdtd3.cu:66-73, fdtdspc.cu:64-73,
 // main.cu:102-133); grids are small so that the run takes a moment.
 #include <cmath>
@@ -43,8 +44,56 @@ static std::vector<float> fetch(S &st, const char *name)
     return h;
 }
 
-int main()
+// 512^3, radius 3, the lambda of fdtd3.cu:69-72 through the functor path and the same update as a closed program
+static int bench()
 {
+    constexpr size_t n = 512;
+    fdtdx::FunctorStencil<float, n, n, n, 3, true, gpu_size_t, gpu_signed_size_t> st;
+    for (const char *c : {"p0", "p1"}) st.mallocCube(c, true);
+    st.initMt("p0", "p1");
+    auto star3 = [=] __device__(gpu_size_t, gpu_size_t, gpu_size_t, gpu_size_t addr, float *output, float *zl, gpu_signed_size_t sz,
+                                float *yl, gpu_signed_size_t sy, float *xl, gpu_signed_size_t sx) {
+        float acc = 0.01f * zl[0];
+        for (int r = 1; r <= 3; r++) {
+            acc += 0.02f * xl[r * sx];
+            acc += 0.03f * xl[-r * sx];
+            acc += 0.04f * yl[r * sy];
+            acc += 0.05f * yl[-r * sy];
+            acc += 0.06f * zl[r * sz];
+            acc += 0.07f * zl[-r * sz];
+        }
+        output[addr] = acc;
+    };
+    const fdtdx_program prog = fdtdx::star_program(3);
+    const int steps = 100;
+    const double cells = double(n - 6) * double(n - 6) * double(n - 6);
+    hipEvent_t e0, e1;
+    FDTDX_HIP_ASSERT(hipEventCreate(&e0));
+    FDTDX_HIP_ASSERT(hipEventCreate(&e1));
+    for (int which = 0; which < 2; which++) {
+        auto step = [&](int t) {
+            const char *out = (t % 2 == 0) ? "p0" : "p1", *in = (t % 2 == 0) ? "p1" : "p0";
+            if (which == 0)
+                st.propagate(out, in, true, star3);
+            else
+                st.propagate(out, in, true, prog);
+        };
+        for (int t = 0; t < 300; t++) step(t);  // the device clock settles over the first tens of milliseconds
+        FDTDX_HIP_ASSERT(hipEventRecord(e0, nullptr));
+        for (int t = 0; t < steps; t++) step(t);
+        FDTDX_HIP_ASSERT(hipEventRecord(e1, nullptr));
+        FDTDX_HIP_ASSERT(hipEventSynchronize(e1));
+        float ms = 0;
+        FDTDX_HIP_ASSERT(hipEventElapsedTime(&ms, e0, e1));
+        std::printf("%-34s %7.1f us per step  %7.1f Gcell/s\n", which == 0 ? "radius-3 lambda (functor path)" : "radius-3 closed program (C ABI)",
+                    ms * 1e3 / steps, cells * steps / (ms * 1e-3) * 1e-9);
+    }
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1 && std::strcmp(argv[1], "bench") == 0) return bench();
     int bad = 0;
     {   // radius-3 star in star mode: registers along z, LDS along y and x
         fdtdx::FunctorStencil<float, nz, ny, nx, 3, true, gpu_size_t, gpu_signed_size_t> st;

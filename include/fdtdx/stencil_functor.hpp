@@ -19,10 +19,10 @@
 //
 // Cubes, transfers, decomposition and halo regions come from fdtdx::Stencil (the C ABI); this
 // header only adds the templated launches, which is why it needs hipcc.  The star-mode kernel is
-// the reference's scheme (one cell per thread, z queue in registers, centre plane in LDS) laid out
-// for wave64: 64 x 8 cell tiles, rows of 256 contiguous bytes per wave, halo rows and columns
-// fetched by a strided loop, one workgroup per tile and z chunk.  It is the general path; the
-// closed programs of fdtdx.h run the tuned kernels.
+// the reference's scheme (z queue in registers, centre plane in LDS) laid out for wave64: tiles of
+// 128 cells x 16 rows, one 16-byte quad per thread, halo rows and quads fetched by a strided loop,
+// the functor called once per cell.  It is the general path (a radius-3 lambda runs at about two thirds of
+// the speed of the closed program); the closed programs of fdtdx.h run the tuned kernels.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -42,49 +42,78 @@ struct FunctorGeom {
 };
 
 // ---- star mode --------------------------------------------------------------------------------------
-template <typename T, int M, int TX, int TY, typename gsz, typename gssz, typename F, typename... Args>
-__global__ __launch_bounds__(TX *TY) void functor_star_kernel(FunctorGeom g, T *out, const T *in, F f, Args... args)
+// A workgroup owns a tile of TXQ quads (4*TXQ cells, x unit-stride) by TY rows and marches a chunk of z planes.
+// A thread owns one quad: it moves 16-byte quads (global loads, LDS image of the current plane with its halo rows
+// and halo quads, double-buffered: one barrier per plane), keeps the z neighbours of its four cells in registers,
+// and calls the functor once per cell with zl into those registers and yl/xl into the LDS image, as the
+// reference's prop_inner/prop_center kernels do (stencil.h:127-289).
+template <typename T, int M, int TXQ, int TY, typename gsz, typename gssz, typename F, typename... Args>
+__global__ __launch_bounds__(TXQ *TY) void functor_star_kernel(FunctorGeom g, T *out, const T *in, F f, Args... args)
 {
-    constexpr int LX = TX + 2 * M, LY = TY + 2 * M, NT = TX * TY;
-    constexpr int NH = 2 * M * TX + 2 * M * TY;  // halo cells: rows above/below, columns left/right (no corners)
-    __shared__ T tile[LY][LX];
-    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-    const int x = M + blockIdx.x * TX + tx, y = M + blockIdx.y * TY + ty;
-    const int zs = g.z_lo + blockIdx.z * g.zchunk;
+    static_assert(sizeof(T) == 4, "quads of four 4-byte cells");
+    constexpr int HQ = (M + 3) / 4;                      // halo quads on each side in x
+    constexpr int LXQ = TXQ + 2 * HQ, LX = 4 * LXQ;      // LDS row: quads, cells
+    constexpr int LY = TY + 2 * M, NT = TXQ * TY;
+    constexpr int NH = 2 * M * TXQ + 2 * HQ * TY;        // halo quads: rows above/below, quads left/right (no corners)
+    __shared__ float4 tile4[2][LY][LXQ];
+    // rows and planes are whole numbers of quads and cubes are 16-byte aligned (fdtdx_geometry): said out loud so
+    // that the compiler may merge what the functor stores for the four cells of a quad
+    __builtin_assume((g.px & 3) == 0);
+    __builtin_assume((g.plane & 3) == 0);
+    out = static_cast<T *>(__builtin_assume_aligned(out, 16));
+    const int tx = threadIdx.x % TXQ, ty = threadIdx.x / TXQ;
+    const int x0 = 4 * ((int)blockIdx.x * TXQ + tx), y = M + (int)blockIdx.y * TY + ty;
+    const int zs = g.z_lo + (int)blockIdx.z * g.zchunk;
     const int ze = min(zs + g.zchunk, g.z_hi);
-    const bool inside = (x < g.nx - M) && (y < g.ny - M);       // this thread's cell is updated
-    const bool loads = (x < g.nx) && (y < g.ny);
-    const long long col = (long long)y * g.px + x;
-    T qz[2 * M + 1];
+    const bool loads = (x0 < g.nx) && (y < g.ny);
+    const bool yin = y < g.ny - M;
+    const long long col = (long long)y * g.px + x0;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    T qz[4][2 * M + 1];  // per cell: planes z-M .. z+M
 #pragma unroll
-    for (int k = 0; k < 2 * M; k++) qz[k + 1] = loads ? in[(long long)(zs - M + k) * g.plane + col] : T(0);
-    for (int z = zs; z < ze; z++) {
+    for (int k = 0; k < 2 * M; k++) {
+        const float4 v = loads ? *reinterpret_cast<const float4 *>(in + (long long)(zs - M + k) * g.plane + col) : zero;
+        qz[0][k + 1] = v.x, qz[1][k + 1] = v.y, qz[2][k + 1] = v.z, qz[3][k + 1] = v.w;
+    }
+    int par = 0;
+    for (int z = zs; z < ze; z++, par ^= 1) {
+        const float4 nv = loads ? *reinterpret_cast<const float4 *>(in + (long long)(z + M) * g.plane + col) : zero;
 #pragma unroll
-        for (int k = 0; k < 2 * M; k++) qz[k] = qz[k + 1];
-        qz[2 * M] = loads ? in[(long long)(z + M) * g.plane + col] : T(0);
-        tile[M + ty][M + tx] = qz[M];
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int k = 0; k < 2 * M; k++) qz[i][k] = qz[i][k + 1];
+        }
+        qz[0][2 * M] = nv.x, qz[1][2 * M] = nv.y, qz[2][2 * M] = nv.z, qz[3][2 * M] = nv.w;
+        tile4[par][M + ty][HQ + tx] = make_float4(qz[0][M], qz[1][M], qz[2][M], qz[3][M]);
         const T *pc = in + (long long)z * g.plane;
         for (int h = threadIdx.x; h < NH; h += NT) {
-            int ly, lx;
-            if (h < 2 * M * TX) {
-                const int r = h / TX;
+            int ly, lq;
+            if (h < 2 * M * TXQ) {
+                const int r = h / TXQ;
                 ly = (r < M) ? r : TY + r;
-                lx = M + h % TX;
+                lq = HQ + h % TXQ;
             } else {
-                const int h2 = h - 2 * M * TX, c = h2 % (2 * M);
-                ly = M + h2 / (2 * M);
-                lx = (c < M) ? c : TX + c;
+                const int h2 = h - 2 * M * TXQ, c = h2 % (2 * HQ);
+                ly = M + h2 / (2 * HQ);
+                lq = (c < HQ) ? c : TXQ + c;
             }
-            const int gy = blockIdx.y * TY + ly, gx = blockIdx.x * TX + lx;  // tile origin is (M, M) in the grid
-            tile[ly][lx] = (gy < g.ny && gx < g.nx) ? pc[(long long)gy * g.px + gx] : T(0);
+            const int gy = (int)blockIdx.y * TY + ly, gq = (int)blockIdx.x * TXQ + lq - HQ;  // tile origin: row M, quad 0
+            tile4[par][ly][lq] = (gy < g.ny && gq >= 0 && 4 * gq < g.nx) ? *reinterpret_cast<const float4 *>(pc + (long long)gy * g.px + 4 * gq) : zero;
         }
-        __syncthreads();
-        if (inside) {
-            const gsz addr = (gsz)((long long)z * g.plane + col);
-            f((gsz)(g.zg0 + z), (gsz)y, (gsz)x, addr, out, &qz[M], (gssz)1, &tile[M + ty][M + tx], (gssz)LX, &tile[M + ty][M + tx], (gssz)1,
-              args...);
+        __syncthreads();  // the other image is only rewritten after the next barrier, when everyone has left this plane's reads behind
+        T *row = reinterpret_cast<T *>(&tile4[par][M + ty][HQ + tx]);
+        const gsz addr0 = (gsz)((long long)z * g.plane + col);
+        auto cell = [&](int i) {
+            f((gsz)(g.zg0 + z), (gsz)y, (gsz)(x0 + i), (gsz)(addr0 + i), out, &qz[i][M], (gssz)1, row + i, (gssz)LX, row + i, (gssz)1, args...);
+        };
+        if (yin && x0 >= M && x0 + 3 < g.nx - M) {
+            // all four cells are interior: one straight block, so that the functor's four stores can go out as one
+            cell(0), cell(1), cell(2), cell(3);
+        } else if (yin) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (x0 + i >= M && x0 + i < g.nx - M) cell(i);
         }
-        __syncthreads();
     }
 }
 
@@ -166,15 +195,15 @@ public:
         DataType *out = this->getCube(output), *in = this->getCube(input);
         FunctorGeom g = geom(z_lo, z_hi);
         if (FDTD) {
-            constexpr int TX = 64, TY = 8;
-            const unsigned gx = (unsigned)((XSize - 2 * M + TX - 1) / TX), gy = (unsigned)((YSize - 2 * M + TY - 1) / TY);
-            // enough z chunks to cover the 256 CUs twice, chunks of at least 8*M planes
+            constexpr int TXQ = 32, TY = 16;  // 128 cells x 16 rows, one quad per thread
+            const unsigned gx = (unsigned)(((XSize + 3) / 4 + TXQ - 1) / TXQ), gy = (unsigned)((YSize - 2 * M + TY - 1) / TY);
+            // about one workgroup of 8 waves per CU and round, chunks of at least 8*M planes (every chunk refills its z queue)
             long long nz = (long long)(z_hi - z_lo), chunks = std::max<long long>(1, 512 / ((long long)gx * gy));
             chunks = std::max<long long>(1, std::min(chunks, nz / (long long)(8 * M)));
             g.zchunk = (int)((nz + chunks - 1) / chunks);
             const unsigned gz = (unsigned)((nz + g.zchunk - 1) / g.zchunk);
-            hipLaunchKernelGGL((functor_star_kernel<DataType, (int)M, TX, TY, gpu_size_t, gpu_signed_size_t, Function, Arguments...>),
-                               dim3(gx, gy, gz), dim3(TX * TY), 0, 0, g, out, in, kernel, args...);
+            hipLaunchKernelGGL((functor_star_kernel<DataType, (int)M, TXQ, TY, gpu_size_t, gpu_signed_size_t, Function, Arguments...>),
+                               dim3(gx, gy, gz), dim3(TXQ * TY), 0, 0, g, out, in, kernel, args...);
         } else {
             const unsigned bx = 256;
             for (uint64_t z = z_lo; z < z_hi; z += 65535) {
