@@ -88,6 +88,47 @@ static int bench()
         std::printf("%-34s %7.1f us per step  %7.1f Gcell/s\n", which == 0 ? "radius-3 lambda (functor path)" : "radius-3 closed program (C ABI)",
                     ms * 1e3 / steps, cells * steps / (ms * 1e-3) * 1e-9);
     }
+    // the 13-point lambda of fdtdspc.cu:64-73 in box mode beside the closed program
+    fdtdx::FunctorStencil<float, n, n, n, 1, false, gpu_size_t, gpu_signed_size_t> sb;
+    for (const char *c : {"p0", "p1"}) sb.mallocCube(c, true);
+    sb.initMt("p0", "p1");
+    auto spc = [=] __device__(gpu_size_t, gpu_size_t, gpu_size_t, gpu_size_t addr, float *output, float *zl, gpu_signed_size_t sz, float *yl,
+                              gpu_signed_size_t sy, float *xl, gpu_signed_size_t sx) {
+        float acc = 0.01f * zl[0];
+        acc += 0.02f * xl[sx];
+        acc += 0.03f * xl[-sx];
+        acc += 0.04f * yl[sy];
+        acc += 0.05f * yl[-sy];
+        acc += 0.06f * zl[sz];
+        acc += 0.07f * zl[-sz];
+        acc += 0.02f * xl[sx + sy];
+        acc += 0.03f * xl[-sx - sy];
+        acc += 0.04f * yl[sy + sz];
+        acc += 0.05f * yl[-sy - sz];
+        acc += 0.06f * zl[sz + sy + sx];
+        acc += 0.07f * zl[-sz - sy - sx];
+        output[addr] = acc;
+    };
+    const fdtdx_program sprog = fdtdx::spc13_program();
+    const double scells = double(n - 2) * double(n - 2) * double(n - 2);
+    for (int which = 0; which < 2; which++) {
+        auto step = [&](int t) {
+            const char *out = (t % 2 == 0) ? "p0" : "p1", *in = (t % 2 == 0) ? "p1" : "p0";
+            if (which == 0)
+                sb.propagate(out, in, true, spc);
+            else
+                sb.propagate(out, in, true, sprog);
+        };
+        for (int t = 0; t < 100; t++) step(t);
+        FDTDX_HIP_ASSERT(hipEventRecord(e0, nullptr));
+        for (int t = 0; t < steps; t++) step(t);
+        FDTDX_HIP_ASSERT(hipEventRecord(e1, nullptr));
+        FDTDX_HIP_ASSERT(hipEventSynchronize(e1));
+        float ms = 0;
+        FDTDX_HIP_ASSERT(hipEventElapsedTime(&ms, e0, e1));
+        std::printf("%-34s %7.1f us per step  %7.1f Gcell/s\n", which == 0 ? "13-point lambda (box mode)" : "13-point closed program (C ABI)",
+                    ms * 1e3 / steps, scells * steps / (ms * 1e-3) * 1e-9);
+    }
     return 0;
 }
 
