@@ -1,7 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- cell-update throughput of the sweep hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--variant fdtd4] [--size 512]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--variant config3|fdtd4|...] [--size 512]
+
+Default workload ("config3"): every radius of the fdtdN drivers (fdtd1.cu .. fdtd8.cu) on the drivers' 512^3
+grid, each timed for K steps; `value` is the SLOWEST of the eight (so the line tracks "every fdtdN above the
+bar"), `variants` holds all eight plus fdtdspc and jacobi.  --variant NAME times that one variant only.
+Started plainly with --gpus N > 1 the script launches its N ranks itself (fresh child processes with
+RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, before anything touches a GPU) and relays rank 0's line; started
+under torch.distributed.run it is one of the ranks.
 
 A "step" is one time step of the drivers' loop (fdtd1.cu:68-80): one sweep of the whole slab
 plus, on N > 1 GPUs, the ghost-plane exchange with the z neighbours.  Weak scaling: every GPU
@@ -12,8 +19,13 @@ before the timed region.  Rank 0 prints ONE JSON line.
 metric   Gcell/s = updated cells x steps / wall seconds (max over ranks), updated cells per
          step = the interior the reference updates (fdtd1.cu:43-45) summed over all ranks.
 roofline bound = HBM; algorithmic traffic 8 B per cell-update (one fp32 read + one fp32 write);
-         achieved = 8 B x cells per launch / average launch duration, measured here with HIP
-         events on the launch stream; peak 8 TB/s.
+         achieved = 8 B x cells x time steps one launch of the dominant kernel advances / that kernel's
+         launch duration, measured here with HIP events on the launch stream over a run of launches of
+         that kernel alone (a fused loop's closing single steps are a different kernel); peak 8 TB/s.
+         A kernel that fuses k steps moves fewer than 8 B per update, so `achieved` can exceed what the
+         memory system delivers; `traffic` (rocprofv3 FETCH_SIZE/WRITE_SIZE per launch of the same
+         kernel, profiles/traffic.json) and `hbm_achieved` = traffic / launch duration say what it
+         really moved.
 spin-up  the device needs 15-30 ms of continuous work after an idle spell (the host-side field generation)
          before its clocks settle: a sweep is up to 1.6x slower in that window.  Before the W warm-up steps
          the same loop therefore runs untimed for --spinup-ms (default 100 ms) and the fields are then put
@@ -100,12 +112,36 @@ def cpu_baseline(kind, radius, n, budget_s=12.0):
             "sample": f"{steps} steps of the {n}^3 loop (oracle/fdtd_oracle.c, gcc -O2 strict IEEE), {dt:.2f} s"}
 
 
+def spawn_ranks(n):
+    """Start n fresh copies of this script, one per GPU, with the rendezvous variables torch.distributed
+    reads; nothing in this (parent) process has touched a GPU.  Rank 0's stdout is relayed; the exit
+    status is non-zero if any rank fails."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0 = procs[0].communicate()[0]
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        raise SystemExit(f"bench.py: ranks failed (rank, exit status): {bad}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--variant", default="jacobi", choices=sorted(VARIANTS))
+    ap.add_argument("--variant", default="config3", choices=["config3"] + sorted(VARIANTS),
+                    help="config3 (default): fdtd1..8 + fdtdspc + jacobi, headline = the slowest fdtdN")
     ap.add_argument("--size", dest="n", type=int, default=512, help="slab edge: every GPU owns n planes of n x n cells")
     ap.add_argument("--grid", default="",
                     help="Z,Y,X of a fixed global grid cut into z-slabs over the ranks (strong scaling, e.g. 2048,1024,1024); "
@@ -115,11 +151,16 @@ def main():
     ap.add_argument("--spinup-ms", type=float, default=100.0,
                     help="untimed device spin-up before the warm-up steps (fields restored afterwards); 0 = none")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-standing-start", dest="standing_start", action="store_false",
+                    help="skip the extra 1000-step run from a standing start (one rank, sweep variants)")
     ap.add_argument("--all-variants", action="store_true", help="also time every other variant (N=1 only)")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="run the N>1 loop with every rank on cuda:0 and host-staged gloo exchange (1-GPU box rehearsal; "
                          "the line is marked rehearsal and is not a measurement)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(a.gpus)  # decided before anything here touches a GPU
 
     import torch
     import torch.distributed as dist
@@ -129,10 +170,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        a.gpus = world
+    a.gpus = world
     if a.rehearse_shared_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -329,36 +367,95 @@ def main():
         cells_rank = float(run.z_hi - run.z_lo) * float(Yg - 2 * radius) * float(Xg - 2 * radius)   # this rank, one step
         cells_all = float(Zg - 2 * radius) * float(Yg - 2 * radius) * float(Xg - 2 * radius)
         info = be.st.lastLaunchInfo()
-        nl_ = launches() - l0
+        nl = launches() - l0
+        res = dict(dt=dt, ev_ms=ev_ms, cells_rank=cells_rank, cells_all=cells_all, info=info, kind=kind, radius=radius, launches=nl)
+        if world == 1:
+            # The dominant kernel by itself: a run of launches of the kernel the loop spends its time in (a fused loop
+            # closes with one to four single steps, which are another kernel), bracketed by HIP events on the launch stream.
+            k = 3 if "fused3" in info else 2 if "fused2" in info else 1
+            lo, hi = run.z_lo, run.z_hi
+            nprobe = max(6, min(60, steps // k))
+
+            def probe(cnt):
+                o, i = "p0", "p1"
+                for _ in range(cnt):
+                    if k == 1:
+                        be.st.propagatePlanes(o, i, prog, lo, hi, cs)
+                    else:
+                        be.st.propagateFusedPlanes(o, i, o, prog, k, lo, hi, cs)
+                    o, i = i, o
+            try:
+                probe(2)
+                e0.record(stream)
+                probe(nprobe)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                res.update(kernel_us=e0.elapsed_time(e1) * 1e3 / nprobe, kernel_steps=k)
+            except Exception:  # no such launch for this program: the loop average stands in
+                pass
+            if a.standing_start:
+                # the drivers' own run: 1000 steps from a standing start (fdtd1.cu:68), device clocks not yet settled
+                torch.cuda.synchronize()
+                time.sleep(1.0)
+                t0 = time.perf_counter()
+                loop(1000)
+                torch.cuda.synchronize()
+                res["standing_start_gcells"] = cells_all * 1000 / (time.perf_counter() - t0) * 1e-9
         be.st.close()
         del be
         torch.cuda.empty_cache()
-        nl = nl_
-        return dict(dt=dt, ev_ms=ev_ms, cells_rank=cells_rank, cells_all=cells_all, info=info, kind=kind, radius=radius,
-                    launches=nl)
+        return res
 
-    r = time_variant(a.variant, a.steps, a.warmup)
-    value = r["cells_all"] * a.steps / r["dt"] * 1e-9
-    # dominant kernel = the sweep.  One launch advances `steps_per_launch` time steps (3 or 2 where a
-    # fused kernel applies, else 1): algorithmic bytes per launch = 8 B x cells x steps per launch,
-    # launch duration = HIP-event time over the timed region / launches issued in it.
-    # On several GPUs a step is split into boundary-plane and interior launches of the same kernel;
-    # the per-launch figures then describe the average of those.
-    nlaunch = r["launches"] or a.steps
-    steps_per_launch = a.steps / nlaunch
-    launch_s = r["ev_ms"] * 1e-3 / nlaunch
-    # bytes per cell-step: main 24 (one fused step); yee3d 48 in one launch (72 as two half steps), yee2d 36 as two launches
-    bpu = {"composite": BYTES_PER_UPDATE_MAIN, "yee3d": 48.0 if a.temporal else 72.0, "yee2d": 36.0}.get(r["kind"], BYTES_PER_UPDATE)
-    achieved = bpu * r["cells_rank"] * steps_per_launch / launch_s * 1e-9
-    traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tf):
-        try:
-            key = a.variant + ("_singlestep" if a.temporal == 0 and VARIANTS[a.variant][1] == 1 and a.variant != "fdtdspc" else "")
-            if world == 1:  # the profiled figure is per whole-slab launch; split launches on several ranks differ
-                traffic = json.load(open(tf)).get(f"{key}_n{a.n}", {}).get("hbm_bytes_per_launch") if not a.grid else None
-        except Exception:
-            traffic = None
+    try:
+        traffic_db = json.load(open(tf))
+    except Exception:
+        traffic_db = {}
+
+    def summarise(name, r, steps):
+        """Per-variant figures: throughput of the timed loop and the roofline position of its dominant kernel."""
+        value = r["cells_all"] * steps / r["dt"] * 1e-9
+        # bytes per cell-step: sweeps 8; main 24 (one fused step); yee3d 48 in one launch (72 as two half steps), yee2d 36 as two launches
+        bpu = {"composite": BYTES_PER_UPDATE_MAIN, "yee3d": 48.0 if a.temporal else 72.0, "yee2d": 36.0}.get(r["kind"], BYTES_PER_UPDATE)
+        if "kernel_us" in r:
+            launch_s, spl = r["kernel_us"] * 1e-6, float(r["kernel_steps"])
+        else:
+            # several ranks (a step is split into boundary-plane and interior launches of the same kernel) and the
+            # pipelines with several kernels per step: average over the launches of the timed region
+            nlaunch = r["launches"] or steps
+            launch_s, spl = r["ev_ms"] * 1e-3 / nlaunch, steps / nlaunch
+        alg = bpu * r["cells_rank"] * spl
+        achieved = alg / launch_s * 1e-9
+        traffic = None
+        key = name + ("_singlestep" if a.temporal == 0 and VARIANTS[name][1] == 1 and name not in ("fdtdspc", "yee3d", "yee2d") else "")
+        ent = traffic_db.get(f"{key}_n{a.n}")
+        # the profiled figure is per whole-slab launch of one named shape: it does not describe split launches on several
+        # ranks, other grids, or a kernel whose shape has changed since it was profiled
+        shape_now = r["info"].rsplit(" launches=", 1)[0]
+        if ent and world == 1 and not a.grid and ent.get("launch_info") in (None, shape_now):
+            traffic = ent.get("hbm_bytes_per_launch")
+        out = {"gcells": round(value, 2), "ms_per_step": round(r["dt"] / steps * 1e3, 5), "launch_us": round(launch_s * 1e6, 2),
+               "steps_per_launch": round(spl, 3), "achieved": round(achieved, 1), "frac": round(achieved / PEAK_HBM_GBS, 4),
+               "algorithmic_bytes_per_launch": alg, "traffic": traffic,
+               "hbm_achieved": round(traffic / launch_s * 1e-9, 1) if traffic else None,
+               "hbm_frac": round(traffic / launch_s * 1e-9 / PEAK_HBM_GBS, 4) if traffic else None,
+               "kernel": shape_now}
+        if "standing_start_gcells" in r:
+            out["standing_start_1000_steps_gcells"] = round(r["standing_start_gcells"], 2)
+        return out
+
+    if a.variant == "config3":
+        names = [f"fdtd{m}" for m in range(1, 9)] + ["fdtdspc", "jacobi"]
+        table, raw = {}, {}
+        for name in names:
+            raw[name] = time_variant(name, a.steps, a.warmup)
+            table[name] = summarise(name, raw[name], a.steps)
+        head = min(names[:8], key=lambda v: table[v]["gcells"])  # the slowest radius carries the line
+    else:
+        names, head = [a.variant], a.variant
+        raw = {head: time_variant(head, a.steps, a.warmup)}
+        table = {head: summarise(head, raw[head], a.steps)}
+    r, t = raw[head], table[head]
 
     grid = [a.n, a.n] if r["kind"] == "yee2d" else [a.n * world, a.n, a.n]
     fixed = bool(a.grid) and r["kind"] in ("star", "spc13", "jacobi7")
@@ -370,22 +467,25 @@ def main():
     elif r["kind"] == "yee2d":
         workload = f"yee2d (extension): ex/ey/hz step on a {a.n}x{a.n} fp32 grid, {a.steps} steps"
     else:
-        workload = (f"{a.variant}: {VARIANTS[a.variant][0]} radius {r['radius']} sweep ({VARIANTS[a.variant][2]}), "
+        workload = (f"{head}: {VARIANTS[head][0]} radius {r['radius']} sweep ({VARIANTS[head][2]}), "
                     f"{grid[0]}x{grid[1]}x{grid[2]} fp32 grid, {a.steps} steps, "
                     + (f"cut into {world} z-slabs" if fixed else f"z-slabs of {a.n} planes per GPU"))
+        if a.variant == "config3":
+            workload = ("fdtd1..fdtd8 (star radius 1..8, fdtd1.cu .. fdtd8.cu) each timed on this grid; value = the slowest, " + workload)
     line = {
-        "metric": "cell-updates/sec", "value": round(value, 2), "unit": "Gcell/s", "n_gpus": world,
-        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(r["dt"] / a.steps * 1e3, 5),
+        "metric": "cell-updates/sec", "value": t["gcells"], "unit": "Gcell/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": t["ms_per_step"],
         "higher_is_better": True, "scaling": "strong" if fixed else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": workload, "grid": grid, "radius": r["radius"], "parallelism": f"zslab{world}", "kernel": r["info"],
+        "config": {"workload": workload, "grid": grid, "radius": r["radius"], "parallelism": f"zslab{world}", "kernel": t["kernel"],
                    "spinup_ms": a.spinup_ms},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                     "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": bpu * r["cells_rank"] * steps_per_launch,
-                     "launches": nlaunch, "steps_per_launch": round(steps_per_launch, 3),
-                     "launch_us": round(launch_s * 1e6, 2)},
+        "roofline": {"bound": "hbm", "achieved": t["achieved"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": t["frac"],
+                     "traffic": t["traffic"], "hbm_achieved": t["hbm_achieved"], "hbm_frac": t["hbm_frac"],
+                     "algorithmic_bytes_per_launch": t["algorithmic_bytes_per_launch"], "steps_per_launch": t["steps_per_launch"],
+                     "launch_us": t["launch_us"]},
     }
-    if a.all_variants and world == 1:
+    if len(names) > 1:
+        line["variants"] = table
+    if a.all_variants and world == 1 and a.variant != "config3":
         others = {}
         for name in sorted(VARIANTS):
             if name == a.variant or name in ("main", "yee3d", "yee2d"):

@@ -100,6 +100,15 @@ struct fdtdx_ctx {
 
 extern "C" const char *fdtdx_last_error(void) { return g_err; }
 
+// Every entry point that touches the GPU first makes the context's device current, so that several
+// contexts in one process (one per GPU, or a thread whose current device is another one) reach the right
+// card.  (The reference never selects a device: one rank sees one GPU, run.sh:20.)
+#define USE_DEVICE(ctx)                                              \
+    do {                                                             \
+        if (!(ctx)) return fail(FDTDX_ERR_INVALID, "null context");  \
+        HIP_TRY(hipSetDevice((ctx)->device));                        \
+    } while (0)
+
 // ---- decomposition (stencil.h:398-412) ---------------------------------------------------------
 extern "C" int fdtdx_decompose(const fdtdx_config *cfg, fdtdx_geometry *out)
 {
@@ -164,6 +173,7 @@ extern "C" int fdtdx_destroy(fdtdx_ctx *ctx)
 {
     if (!ctx) return FDTDX_OK;
     int rc = FDTDX_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
     for (auto &kv : ctx->pool)
         if (kv.second.owned && kv.second.ptr && hipFree(kv.second.ptr) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(%s) failed", kv.first.c_str());
     if (ctx->tb_scratch && hipFree(ctx->tb_scratch) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(scratch) failed");
@@ -186,7 +196,7 @@ extern "C" int fdtdx_nprocs(const fdtdx_ctx *ctx) { return ctx ? (int)ctx->cfg.n
 
 extern "C" int fdtdx_sync(fdtdx_ctx *ctx)
 {
-    if (!ctx) return fail(FDTDX_ERR_INVALID, "null context");
+    USE_DEVICE(ctx);
     HIP_TRY(hipDeviceSynchronize());
     return FDTDX_OK;
 }
@@ -196,6 +206,7 @@ extern "C" int fdtdx_malloc_cube(fdtdx_ctx *ctx, const char *name)
 {
     if (!ctx || !name) return fail(FDTDX_ERR_INVALID, "null argument");
     if (ctx->pool.count(name)) return fail(FDTDX_ERR_EXISTS, "cube '%s' already exists (stencil.h:555)", name);
+    USE_DEVICE(ctx);
     float *p = nullptr;
     size_t bytes = ctx->g.cube_elems * sizeof(float);
     HIP_TRY(hipMalloc((void **)&p, bytes));
@@ -230,6 +241,7 @@ extern "C" int fdtdx_free(fdtdx_ctx *ctx, const char *name)
     if (!ctx || !name) return fail(FDTDX_ERR_INVALID, "null argument");
     auto it = ctx->pool.find(name);
     if (it == ctx->pool.end()) return fail(FDTDX_ERR_NOTFOUND, "no cube '%s' (stencil.h:470)", name);
+    USE_DEVICE(ctx);
     if (it->second.owned) HIP_TRY(hipFree(it->second.ptr));
     ctx->pool.erase(it);
     return FDTDX_OK;
@@ -253,6 +265,7 @@ extern "C" int fdtdx_get_cube(fdtdx_ctx *ctx, const char *name, float **device_p
 // ---- transfers (stencil.h:596-637): pitch conversion done by the copy engine -------------------
 static int copy_planes_h2d(fdtdx_ctx *ctx, float *dev, const float *host, uint64_t nplanes)
 {
+    USE_DEVICE(ctx);
     const fdtdx_geometry &g = ctx->g;
     const uint64_t X = ctx->cfg.X, Y = ctx->cfg.Y;
     HIP_TRY(hipMemcpy2D(dev, g.pitch_x * sizeof(float), host, X * sizeof(float), X * sizeof(float), nplanes * Y, hipMemcpyHostToDevice));
@@ -260,6 +273,10 @@ static int copy_planes_h2d(fdtdx_ctx *ctx, float *dev, const float *host, uint64
 }
 static int copy_planes_d2h(fdtdx_ctx *ctx, float *host, const float *dev, uint64_t nplanes)
 {
+    USE_DEVICE(ctx);
+    // stencil.h:615: the reference synchronises the device before it copies a cube back; sweeps queued on
+    // any stream (non-blocking ones included) have finished when the copy reads the cube
+    HIP_TRY(hipDeviceSynchronize());
     const fdtdx_geometry &g = ctx->g;
     const uint64_t X = ctx->cfg.X, Y = ctx->cfg.Y;
     HIP_TRY(hipMemcpy2D(host, X * sizeof(float), dev, g.pitch_x * sizeof(float), X * sizeof(float), nplanes * Y, hipMemcpyDeviceToHost));
@@ -313,6 +330,7 @@ extern "C" int fdtdx_init_mt(fdtdx_ctx *ctx, const char *name_p0, const char *na
     if (rc) return rc;
     rc = find_cube(ctx, name_p1, &d1);
     if (rc) return rc;
+    USE_DEVICE(ctx);
     const fdtdx_geometry &g = ctx->g;
     const uint64_t X = ctx->cfg.X, Y = ctx->cfg.Y;
     // stage a bounded number of planes at a time so host memory stays small for big slabs
@@ -348,6 +366,7 @@ extern "C" int fdtdx_init_jacobi(fdtdx_ctx *ctx, const char *name)
     float *d;
     int rc = find_cube(ctx, name, &d);
     if (rc) return rc;
+    USE_DEVICE(ctx);
     const fdtdx_geometry &g = ctx->g;
     const uint64_t X = ctx->cfg.X, Y = ctx->cfg.Y;
     std::vector<float> h(Y * X);
@@ -418,6 +437,7 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
     }
     rc = check_program(ctx, prog, &r);
     if (rc) return rc;
+    USE_DEVICE(ctx);
     const fdtdx_geometry &g = ctx->g;
     if (z_lo < (uint64_t)r || z_hi > g.local_planes - r || z_lo > z_hi)
         return fail(FDTDX_ERR_INVALID, "plane range [%llu,%llu) outside [%d,%llu)", (unsigned long long)z_lo, (unsigned long long)z_hi, r, (unsigned long long)(g.local_planes - r));
@@ -568,6 +588,7 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
 {
     const fdtdx_geometry &g = ctx->g;
     if (z_lo >= z_hi) return FDTDX_OK;
+    USE_DEVICE(ctx);
     TbParams p;
     p.in = in, p.mid = mid, p.out = out;
     p.plane = (long long)g.plane;
@@ -712,7 +733,16 @@ extern "C" int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const f
         uint32_t pairs = (steps % 2 == 0) ? steps / 2 - 1 : ((steps - 1) / 2) & ~1u;
         if (pairs > 0) {
             const size_t bytes = g.cube_elems * sizeof(float);
-            if (!ctx->tb_scratch) HIP_TRY(hipMalloc((void **)&ctx->tb_scratch, bytes));
+            USE_DEVICE(ctx);
+            if (!ctx->tb_scratch && hipMalloc((void **)&ctx->tb_scratch, bytes) != hipSuccess) {
+                // no room for the third cube: run the loop as single steps (same results)
+                (void)hipGetLastError();
+                ctx->tb_scratch = nullptr;
+                pairs = 0;
+            }
+        }
+        if (pairs > 0) {
+            const size_t bytes = g.cube_elems * sizeof(float);
             HIP_TRY(hipMemcpyAsync(ctx->tb_scratch, pb, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
             float *cur = pb, *oth = ctx->tb_scratch;
             for (uint32_t k = 0; k < pairs; k++) {
@@ -832,6 +862,7 @@ extern "C" int fdtdx_inject(fdtdx_ctx *ctx, const char *cube, const char *addr_n
     if (it == ctx->addr.end()) return fail(FDTDX_ERR_NOTFOUND, "no address list '%s'", addr_name);
     const uint64_t n = it->second.count;
     if (n == 0 || z_lo == z_hi) return FDTDX_OK;
+    USE_DEVICE(ctx);
     hipLaunchKernelGGL(inject_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pc, it->second.ptr, n, add,
                        ctx->g.plane, z_lo, z_hi);
     HIP_TRY(hipGetLastError());
@@ -882,6 +913,7 @@ __global__ void filt_planes_kernel(float *cube, long long plane, int px, int nx,
 static int launch_filt(fdtdx_ctx *ctx, float *pc, uint64_t z_lo, uint64_t z_hi, int64_t zsel, int64_t ysel, int64_t xsel, double scale, int golden,
                        float *sum, const float *other, int h, uint64_t mz_lo, uint64_t mz_hi, hipStream_t s)
 {
+    USE_DEVICE(ctx);
     const fdtdx_geometry &g = ctx->g;
     const long long nz = (long long)(z_hi - z_lo), ny = (long long)ctx->cfg.Y;
     const long long cell_blocks = (nz * ny + 255) / 256, row_blocks = (ny + nz + 3) / 4;
@@ -928,48 +960,75 @@ extern "C" int fdtdx_filt_planes(fdtdx_ctx *ctx, const char *cube, int64_t zsel,
 
 // One whole step of main.cu:160-163 on the planes this rank owns, with the product-accumulate folded
 // into the update kernel (24 instead of 32 bytes per cell); results are those of the four separate calls.
-extern "C" int fdtdx_composite_step(fdtdx_ctx *ctx, const char *out, const char *in, const char *vel, const char *sum, const char *addr_name,
-                                    const fdtdx_composite *comp, float add, int64_t zsel, int64_t ysel, int64_t xsel, double scale,
-                                    void *stream)
+// `saved` receives one float per listed address (the sum values before the step); the two entry points
+// below differ only in where that buffer lives.
+struct CompositeStepArgs {
+    float *po, *pi, *pv, *ps;
+    const uint64_t *addr;
+    uint64_t n;
+};
+
+static int composite_step_check(fdtdx_ctx *ctx, const char *out, const char *in, const char *vel, const char *sum, const char *addr_name,
+                                const fdtdx_composite *comp, CompositeStepArgs *a)
 {
     if (!ctx || !comp || !addr_name) return fail(FDTDX_ERR_INVALID, "null argument");
-    float *po, *pi, *pv, *ps;
     int rc;
-    if ((rc = find_cube(ctx, out, &po)) || (rc = find_cube(ctx, in, &pi)) || (rc = find_cube(ctx, vel, &pv)) || (rc = find_cube(ctx, sum, &ps)))
+    if ((rc = find_cube(ctx, out, &a->po)) || (rc = find_cube(ctx, in, &a->pi)) || (rc = find_cube(ctx, vel, &a->pv)) ||
+        (rc = find_cube(ctx, sum, &a->ps)))
         return rc;
-    if (po == pv || ps == po || ps == pi || ps == pv || po == pi) return fail(FDTDX_ERR_INVALID, "composite step needs four different cubes");
+    if (a->po == a->pv || a->ps == a->po || a->ps == a->pi || a->ps == a->pv || a->po == a->pi)
+        return fail(FDTDX_ERR_INVALID, "composite step needs four different cubes");
     if (comp->scal_den == 0.0) return fail(FDTDX_ERR_INVALID, "scal_den is zero");
     auto it = ctx->addr.find(addr_name);
     if (it == ctx->addr.end()) return fail(FDTDX_ERR_NOTFOUND, "no address list '%s'", addr_name);
+    a->addr = it->second.ptr;
+    a->n = it->second.count;
+    return FDTDX_OK;
+}
+
+static int composite_step_run(fdtdx_ctx *ctx, const CompositeStepArgs &a, const char *out, const char *addr_name, const fdtdx_composite *comp,
+                              float add, int64_t zsel, int64_t ysel, int64_t xsel, double scale, float *saved, void *stream)
+{
     const fdtdx_geometry &g = ctx->g;
-    const uint64_t r = comp->radius, n = it->second.count;
+    const uint64_t r = comp->radius, n = a.n;
     const uint64_t lo = g.ghost_lo ? g.ghost_lo : r, hi = g.ghost_hi ? g.local_planes - g.ghost_hi : g.local_planes - r;
     const uint64_t olo = g.ghost_lo, ohi = g.ghost_lo + g.owned_planes;
     const int golden = comp->order == FDTDX_ORDER_GOLDEN ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(hipSetDevice(ctx->device));
-    if (n > ctx->saved_cap) {
-        if (ctx->saved_sum) HIP_TRY(hipFree(ctx->saved_sum));
-        ctx->saved_sum = nullptr, ctx->saved_cap = 0;
-        HIP_TRY(hipMalloc((void **)&ctx->saved_sum, n * sizeof(float)));
-        ctx->saved_cap = n;
-    }
-    if (n) {
-        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ctx->saved_sum, ps, it->second.ptr, n);
+    int rc;
+    if (n) {  // every word of `saved` the step reads is written here first
+        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, saved, (const float *)a.ps, a.addr, n);
         HIP_TRY(hipGetLastError());
     }
     const int64_t sel[3] = {zsel, ysel, xsel};
-    if ((rc = launch_sweep(ctx, po, pi, nullptr, lo, hi, stream, comp, pv, ps, sel))) return rc;
+    if ((rc = launch_sweep(ctx, a.po, a.pi, nullptr, lo, hi, stream, comp, a.pv, a.ps, sel))) return rc;
     if ((rc = fdtdx_inject(ctx, out, addr_name, add, olo, ohi, stream))) return rc;
-    if (ohi > olo && (rc = launch_filt(ctx, po, olo, ohi, zsel, ysel, xsel, scale, golden, ps, pi, (int)r, lo, hi, s))) return rc;
+    if (ohi > olo && (rc = launch_filt(ctx, a.po, olo, ohi, zsel, ysel, xsel, scale, golden, a.ps, a.pi, (int)r, lo, hi, s))) return rc;
     if (n) {
-        hipLaunchKernelGGL(redo_product_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ps, (const float *)ctx->saved_sum,
-                           (const float *)po, (const float *)pi, (const uint64_t *)it->second.ptr, n, (long long)g.plane, (int)g.pitch_x,
-                           (int)ctx->cfg.X, (int)ctx->cfg.Y, (int)r, (long long)lo, (long long)hi, (long long)g.first_global, (long long)zsel,
-                           (long long)ysel, (long long)xsel, golden);
+        hipLaunchKernelGGL(redo_product_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.ps, (const float *)saved,
+                           (const float *)a.po, (const float *)a.pi, a.addr, n, (long long)g.plane, (int)g.pitch_x, (int)ctx->cfg.X,
+                           (int)ctx->cfg.Y, (int)r, (long long)lo, (long long)hi, (long long)g.first_global, (long long)zsel, (long long)ysel,
+                           (long long)xsel, golden);
         HIP_TRY(hipGetLastError());
     }
     return FDTDX_OK;
+}
+
+extern "C" int fdtdx_composite_step(fdtdx_ctx *ctx, const char *out, const char *in, const char *vel, const char *sum, const char *addr_name,
+                                    const fdtdx_composite *comp, float add, int64_t zsel, int64_t ysel, int64_t xsel, double scale,
+                                    void *stream)
+{
+    CompositeStepArgs a;
+    int rc = composite_step_check(ctx, out, in, vel, sum, addr_name, comp, &a);
+    if (rc) return rc;
+    USE_DEVICE(ctx);
+    if (a.n > ctx->saved_cap) {
+        if (ctx->saved_sum) HIP_TRY(hipFree(ctx->saved_sum));
+        ctx->saved_sum = nullptr, ctx->saved_cap = 0;
+        HIP_TRY(hipMalloc((void **)&ctx->saved_sum, a.n * sizeof(float)));
+        ctx->saved_cap = a.n;
+    }
+    return composite_step_run(ctx, a, out, addr_name, comp, add, zsel, ysel, xsel, scale, ctx->saved_sum, stream);
 }
 
 // sum += a*b on the interior: one quad per lane; grid = (quad blocks, interior rows, planes)
@@ -1002,6 +1061,7 @@ extern "C" int fdtdx_mul_acc(fdtdx_ctx *ctx, const char *sum, const char *a, con
     const uint64_t X = ctx->cfg.X, Y = ctx->cfg.Y;
     if (radius < 1 || 2 * (uint64_t)radius >= Y || 2 * (uint64_t)radius >= X) return fail(FDTDX_ERR_INVALID, "radius %u leaves no interior", radius);
     if (Y - 2 * radius > 65535) return fail(FDTDX_ERR_UNSUPPORTED, "more than 65535 interior rows");
+    USE_DEVICE(ctx);
     const fdtdx_geometry &g = ctx->g;
     const int nq = (int)((X + 3) / 4);
     for (uint64_t z = z_lo; z < z_hi; z += 65535) {  // planes go to the grid's z dimension
@@ -1031,6 +1091,7 @@ extern "C" int fdtdx_yee3d_half(fdtdx_ctx *ctx, const char *const fields[6], int
             if (p.f[k] == p.f[i]) return fail(FDTDX_ERR_INVALID, "the six fields must be six different cubes");
     }
     if (z_lo == z_hi) return FDTDX_OK;
+    USE_DEVICE(ctx);
     p.plane = (long long)g.plane, p.px = (int)g.pitch_x, p.nx = (int)ctx->cfg.X, p.ny = (int)ctx->cfg.Y;
     p.z_lo = (int)z_lo, p.z_hi = (int)z_hi, p.coef = coef;
     const unsigned gx = (unsigned)(((ctx->cfg.X + 3) / 4 + 63) / 64), gy = (unsigned)((ctx->cfg.Y - 2 + 3) / 4);
@@ -1076,6 +1137,7 @@ extern "C" int fdtdx_yee3d_step_fused(fdtdx_ctx *ctx, const char *const before[6
         for (int k = 0; k < i; k++)
             if (f[k] == f[i]) return fail(FDTDX_ERR_INVALID, "the fused step needs twelve different cubes (six before, six after)");
     }
+    USE_DEVICE(ctx);
     for (int i = 0; i < 3; i++) p.eo[i] = f[i], p.ho[i] = f[3 + i], p.en[i] = f[6 + i], p.hn[i] = f[9 + i];
     p.plane = (long long)g.plane, p.px = (int)g.pitch_x, p.nx = (int)ctx->cfg.X, p.ny = (int)ctx->cfg.Y, p.nz = (int)g.local_planes;
     p.z_lo = 1, p.z_hi = (int)g.local_planes - 1, p.ce = ce, p.ch = ch;

@@ -35,6 +35,8 @@ def gpu_run(kind, M, a, b, steps):
 
 
 @pytest.mark.parametrize("kind,M,steps", [("star", 1, 3), ("star", 4, 2), ("star", 8, 2), ("spc13", 1, 2), ("jacobi7", 1, 3),
+                                           # the remaining radii at the drivers' size: their default tile shapes and z chunking
+                                           ("star", 3, 2), ("star", 5, 2), ("star", 6, 2), ("star", 7, 2),
                                            # four steps and more run through the fused kernels (three steps per launch at
                                            # radius 1, two at radius 2) and finish with single steps
                                            ("star", 1, 7), ("jacobi7", 1, 8), ("star", 2, 6)])

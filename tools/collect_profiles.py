@@ -25,8 +25,13 @@ for spec in sys.argv[2:]:
     json.dump(summ, open(base + "_summary.json", "w"), indent=1)
     for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
         shutil.copy(f, base + "_kernel_stats.csv")
+    try:  # the shape bench.py reported for the profiled run: bench.py drops the figure when the kernel's shape has changed since
+        line = [l for l in open(os.path.join(src, "trace.log")) if l.startswith("{")][-1]
+        launch_info = json.loads(line)["config"]["kernel"].rsplit(" launches=", 1)[0]
+    except Exception:
+        launch_info = None
     traffic[f"{variant}_n512"] = {
-        "kernel": summ.get("kernel"), "avg_us": summ.get("avg_us"), "timed_avg_us": summ.get("timed_avg_us"),
+        "kernel": summ.get("kernel"), "launch_info": launch_info, "avg_us": summ.get("avg_us"), "timed_avg_us": summ.get("timed_avg_us"),
         "hbm_bytes_per_launch": summ.get("hbm_bytes_per_launch"),
         "read_bytes_corrected": summ.get("read_bytes_corrected"), "write_bytes": summ.get("write_bytes"),
         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, units of 1024 B; FETCH_SIZE doubled "
