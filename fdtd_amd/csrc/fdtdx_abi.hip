@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <random>
 #include <string>
 #include <thread>
@@ -93,6 +94,7 @@ struct fdtdx_ctx {
     float *tb_scratch = nullptr;       // third cube of the fused time loop (owned)
     float *saved_sum = nullptr;        // fdtdx_composite_step: sum values at the injection addresses
     size_t saved_cap = 0;
+    float *static_scratch = nullptr;   // device address of the file-scope `scratch` array on ctx->device
     uint64_t launches = 0;             // sweep launches issued so far (bench bookkeeping)
     char last_launch[256] = "";
     char last_fused[256] = "";         // last fused (two-step) launch, "" if none since creation
@@ -148,6 +150,33 @@ extern "C" int fdtdx_decompose(const fdtdx_config *cfg, fdtdx_geometry *out)
     return FDTDX_OK;
 }
 
+// ---- scratch of the entry point that allocates nothing (fdtdx_composite_step_static) ------------------
+// One float per listed injection address.  The array is part of the code object, so every GPU the library
+// runs on holds its own copy, at its own address, until the process ends.  In host code the array's NAME is
+// only a handle for hipGetSymbolAddress: the device address is asked for once per device (below, from
+// fdtdx_create with that device current) and only that address is ever handed to kernels.
+// (No `used` attribute on it: that makes the symbol local to the code object, and the runtime's lookup
+// by name then aborts the process instead of returning an error.)
+static __device__ __align__(256) float scratch[FDTDX_STATIC_ADDR_MAX];
+constexpr int kMaxDevices = 64;
+static float *g_scratch_addr[kMaxDevices];  // per device: where `scratch` lives there (nullptr: not asked yet)
+static std::mutex g_scratch_mutex;
+
+// the calling thread's current device must be `dev`
+static int scratch_address(int dev, float **out)
+{
+    if (dev < 0 || dev >= kMaxDevices) return fail(FDTDX_ERR_UNSUPPORTED, "device ordinal %d outside 0..%d", dev, kMaxDevices - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_addr[dev]) {
+        float *ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) return fail(FDTDX_ERR_HIP, "hipGetSymbolAddress(scratch) on device %d: %s", dev, hipGetErrorString(e));
+        g_scratch_addr[dev] = ptr;
+    }
+    *out = g_scratch_addr[dev];
+    return FDTDX_OK;
+}
+
 extern "C" int fdtdx_create(const fdtdx_config *cfg, fdtdx_ctx **out)
 {
     if (!cfg || !out) return fail(FDTDX_ERR_INVALID, "null argument");
@@ -165,6 +194,9 @@ extern "C" int fdtdx_create(const fdtdx_config *cfg, fdtdx_ctx **out)
     c->cfg = *cfg;
     c->g = g;
     c->device = dev;
+    // set-up of the static scratch for this device (device `dev` is current here); a failure is kept for
+    // fdtdx_composite_step_static to report, every other entry point works without the array
+    if (scratch_address(dev, &c->static_scratch) != FDTDX_OK) c->static_scratch = nullptr;
     *out = c;
     return FDTDX_OK;
 }
@@ -1029,6 +1061,26 @@ extern "C" int fdtdx_composite_step(fdtdx_ctx *ctx, const char *out, const char 
         ctx->saved_cap = a.n;
     }
     return composite_step_run(ctx, a, out, addr_name, comp, add, zsel, ysel, xsel, scale, ctx->saved_sum, stream);
+}
+
+// The same step for callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid hipMalloc):
+// the per-address buffer is the file-scope `scratch` array instead of context memory.  No hipMalloc, hipFree or other
+// allocating routine is called on this path.  All calls on one GPU share that GPU's array, so calls that overlap
+// on one GPU (two streams, two contexts) race; every word a call reads from the array it has written itself
+// earlier in the same call (the gather), so nothing has to be cleared between calls.
+extern "C" int fdtdx_composite_step_static(fdtdx_ctx *ctx, const char *out, const char *in, const char *vel, const char *sum,
+                                           const char *addr_name, const fdtdx_composite *comp, float add, int64_t zsel, int64_t ysel,
+                                           int64_t xsel, double scale, void *stream)
+{
+    CompositeStepArgs a;
+    int rc = composite_step_check(ctx, out, in, vel, sum, addr_name, comp, &a);
+    if (rc) return rc;
+    if (a.n > FDTDX_STATIC_ADDR_MAX)
+        return fail(FDTDX_ERR_UNSUPPORTED, "address list '%s' holds %llu addresses on this rank, the static scratch holds %llu: use fdtdx_composite_step",
+                    addr_name, (unsigned long long)a.n, (unsigned long long)FDTDX_STATIC_ADDR_MAX);
+    USE_DEVICE(ctx);
+    if (!ctx->static_scratch && (rc = scratch_address(ctx->device, &ctx->static_scratch))) return rc;
+    return composite_step_run(ctx, a, out, addr_name, comp, add, zsel, ysel, xsel, scale, ctx->static_scratch, stream);
 }
 
 // sum += a*b on the interior: one quad per lane; grid = (quad blocks, interior rows, planes)

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FDTDX_LIB names another build of the same library (tuning experiments)
 LIB_PATH = os.environ.get("FDTDX_LIB") or os.path.join(_HERE, "libfdtdx.so")
 
+STATIC_ADDR_MAX = 262144  # FDTDX_STATIC_ADDR_MAX
 OK, ERR_INVALID, ERR_NOTFOUND, ERR_EXISTS, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM = range(7)
 STAR, SPC13, JACOBI7 = 0, 1, 2
 ORDER_CHAIN, ORDER_GOLDEN = 0, 1
@@ -83,6 +84,8 @@ SYMBOLS = {
     "fdtdx_propagate_composite": (ctypes.c_int, [_vp, _c, _c, _c, _P(Composite), _vp]),
     "fdtdx_composite_step": (ctypes.c_int, [_vp, _c, _c, _c, _c, _c, _P(Composite), ctypes.c_float, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_int64, ctypes.c_double, _vp]),
+    "fdtdx_composite_step_static": (ctypes.c_int, [_vp, _c, _c, _c, _c, _c, _P(Composite), ctypes.c_float, ctypes.c_int64, ctypes.c_int64,
+                                                   ctypes.c_int64, ctypes.c_double, _vp]),
     "fdtdx_malloc_addr": (ctypes.c_int, [_vp, _c, ctypes.c_uint64]),
     "fdtdx_transfer_addr_to_gpu": (ctypes.c_int, [_vp, _c, _P(ctypes.c_uint64), ctypes.c_uint64]),
     "fdtdx_addr_size": (ctypes.c_int, [_vp, _c, _P(ctypes.c_uint64)]),

@@ -150,6 +150,13 @@ class Stencil:
                                                 addr_name.encode(), ctypes.byref(comp), add, zsel, ysel, xsel, scale,
                                                 ctypes.c_void_p(stream or 0)))
 
+    def compositeStepStatic(self, output, input, vel, sum_name, addr_name, comp, add, zsel, ysel, xsel, scale, stream=None):
+        """compositeStep without any device allocation (scratch in a static device array; at most
+        lib.STATIC_ADDR_MAX listed addresses on this rank)."""
+        _lib.check(self._L.fdtdx_composite_step_static(self._h, output.encode(), input.encode(), vel.encode(), sum_name.encode(),
+                                                       addr_name.encode(), ctypes.byref(comp), add, zsel, ysel, xsel, scale,
+                                                       ctypes.c_void_p(stream or 0)))
+
     def mallocAddr(self, name, capacity):
         """malloc<size_t>(name, n, true), stencil.h:446-466."""
         _lib.check(self._L.fdtdx_malloc_addr(self._h, name.encode(), capacity))

@@ -226,6 +226,18 @@ int fdtdx_composite_step(fdtdx_ctx *ctx, const char *out, const char *in, const 
                          const char *addr_name, const fdtdx_composite *comp, float add, int64_t zsel, int64_t ysel,
                          int64_t xsel, double scale, void *stream);
 
+/* fdtdx_composite_step for callers that cannot allocate device memory: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, same results bit for bit;
+ * the one buffer the step needs beyond its cubes (one float per listed address) is a file-scope device array of
+ * FDTDX_STATIC_ADDR_MAX floats (1 MiB, held on every GPU the library runs on until the process ends) instead of
+ * memory allocated inside the context, and the call allocates nothing.  A list with more addresses on this rank is
+ * rejected with FDTDX_ERR_UNSUPPORTED.  All calls on one GPU share that GPU's array: calls that overlap in time on
+ * one GPU (different streams or contexts) race; calls ordered on one stream do not. */
+#define FDTDX_STATIC_ADDR_MAX 262144u
+int fdtdx_composite_step_static(fdtdx_ctx *ctx, const char *out, const char *in, const char *vel, const char *sum,
+                                const char *addr_name, const fdtdx_composite *comp, float add, int64_t zsel, int64_t ysel,
+                                int64_t xsel, double scale, void *stream);
+
 /* ---- extension: staggered-grid E/H updates -----------------------------------------------------------
  * The reference has no E/H kernels (its drivers are scalar ping-pong stencils); these entry points have no
  * counterpart in it and are defined by this library alone (CPU restatement: oracle/fdtd_oracle.c).
