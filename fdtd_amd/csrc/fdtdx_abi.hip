@@ -592,17 +592,22 @@ extern "C" int fdtdx_propagate(fdtdx_ctx *ctx, const char *out, const char *in, 
     return fdtdx_propagate_planes(ctx, out, in, prog, lo, hi, stream);
 }
 
-// Fused steps (tb_kernel.h): out = f^kt(in), kt = 2 or 3, shell cells of the odd levels from `mid`.
+// Fused steps (tb_kernel.h, tbm_kernel.h, tbs_kernel.h): out = f^kt(in), kt = 2 or 3, shell cells of the odd levels from `mid`.
 static const TbVariantInfo *pick_tb(const fdtdx_ctx *ctx, const fdtdx_program *prog, int kt)
 {
-    if (prog->order != FDTDX_ORDER_CHAIN) return nullptr;
+    const bool golden = prog->order == FDTDX_ORDER_GOLDEN;
     int ord;
     const int radius = prog->kind == FDTDX_STAR ? (int)prog->radius : 1;
     if (prog->kind == FDTDX_STAR)
-        ord = ORD_STAR_CHAIN;
+        ord = golden ? ORD_STAR_GOLDEN : ORD_STAR_CHAIN;
     else if (prog->kind == FDTDX_JACOBI7)
-        ord = ORD_JACOBI_CHAIN;
-    else
+        ord = golden ? ORD_JACOBI_GOLDEN : ORD_JACOBI_CHAIN;
+    else if (prog->kind == FDTDX_SPC13) {
+        ord = golden ? ORD_SPC_GOLDEN : ORD_SPC_CHAIN;
+        // the fused 13-point kernel keeps one shell quad per lane and row: rows of exactly 65 quads would put the first
+        // and the last quad of a row (both with a shell cell) into one lane; such grids run single steps
+        if ((ctx->cfg.X + 3) / 4 == 65) return nullptr;
+    } else
         return nullptr;
     const TbVariantInfo *best = nullptr;
     int idx = 0;
@@ -616,19 +621,21 @@ static const TbVariantInfo *pick_tb(const fdtdx_ctx *ctx, const fdtdx_program *p
 }
 
 static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const float *in, const float *mid, const fdtdx_program *prog,
-                     uint64_t z_lo, uint64_t z_hi, void *stream)
+                     uint64_t z_lo, uint64_t z_hi, void *stream, const float *even = nullptr)
 {
     const fdtdx_geometry &g = ctx->g;
     if (z_lo >= z_hi) return FDTDX_OK;
     USE_DEVICE(ctx);
     TbParams p;
     p.in = in, p.mid = mid, p.out = out;
+    p.even = even ? even : in;
+    if (p.even != in && !v->shells) return fail(FDTDX_ERR_UNSUPPORTED, "this fused kernel takes its level-0 shell from `in` only");
     p.plane = (long long)g.plane;
     p.px = (int)g.pitch_x, p.pxq = (int)(g.pitch_x / 4);
     p.nx = (int)ctx->cfg.X, p.ny = (int)ctx->cfg.Y, p.nz = (int)g.local_planes;
     p.zg0 = (int)g.first_global, p.nzg = (int)ctx->cfg.Z;
     p.z_lo = (int)z_lo, p.z_hi = (int)z_hi;
-    memcpy(p.c, prog->coef, 7 * sizeof(float));
+    memcpy(p.c, prog->coef, 13 * sizeof(float));
     const int reach = v->kt * v->radius;  // cells a fused launch reaches on each side
     const int owned = v->nw * v->ry - 2 * reach;
     p.gy = (p.ny - 2 * v->radius + owned - 1) / owned;
@@ -693,28 +700,46 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
     return FDTDX_OK;
 }
 
-extern "C" int fdtdx_propagate_fused_planes(fdtdx_ctx *ctx, const char *out, const char *in, const char *mid, const fdtdx_program *prog,
-                                            uint32_t nsteps, uint64_t z_lo, uint64_t z_hi, void *stream)
+// out = f^nsteps(in*), in* = in with the shell of `even`; the odd intermediate levels take their shell from `odd`,
+// the even ones from `even`; the shell of `out` is not written
+static int fused_launch_checked(fdtdx_ctx *ctx, const char *out, const char *in, const char *even, const char *odd, const fdtdx_program *prog,
+                                uint32_t nsteps, uint64_t z_lo, uint64_t z_hi, void *stream)
 {
     if (!ctx) return fail(FDTDX_ERR_INVALID, "null context");
     int r;
     int rc = check_program(ctx, prog, &r);
     if (rc) return rc;
     if (nsteps != 2 && nsteps != 3) return fail(FDTDX_ERR_UNSUPPORTED, "fused sweeps advance 2 or 3 steps, not %u", nsteps);
-    float *po, *pi, *pm;
-    if ((rc = find_cube(ctx, out, &po)) || (rc = find_cube(ctx, in, &pi)) || (rc = find_cube(ctx, mid, &pm))) return rc;
-    // three steps end on an odd level, whose shell is the one `mid` carries: out may be mid itself
-    // (shell cells are only read, interior cells only written)
-    if (po == pi || pm == pi || (po == pm && nsteps == 2)) return fail(FDTDX_ERR_INVALID, "fused sweep cannot write a cube it reads");
+    float *po, *pi, *pe, *pm;
+    if ((rc = find_cube(ctx, out, &po)) || (rc = find_cube(ctx, in, &pi)) || (rc = find_cube(ctx, even, &pe)) || (rc = find_cube(ctx, odd, &pm)))
+        return rc;
     const TbVariantInfo *tb = pick_tb(ctx, prog, (int)nsteps);
-    if (!tb) return fail(FDTDX_ERR_UNSUPPORTED, "no fused kernel for this program (device order; radius 1: 2 or 3 steps, radius 2: 2 steps)");
+    if (!tb)
+        return fail(FDTDX_ERR_UNSUPPORTED, "no fused kernel for this program (radius 1 star/jacobi: 2 or 3 steps; radius 2 star, 13-point: 2 steps)");
+    // a launch reads interior cells of `in` and shell cells of `even`/`odd`, and writes interior cells of `out`: `out` may be one of the
+    // shell sources, never `in`.  Kernels that rewrite the shell cells of partly stored quads need `out` to carry the shell of its level.
+    if (po == pi) return fail(FDTDX_ERR_INVALID, "fused sweep cannot write the cube it reads");
+    if (!tb->shells && (pe != pi || pm == pi || (po == pm && nsteps == 2)))
+        return fail(FDTDX_ERR_UNSUPPORTED, "this fused kernel takes the even levels' shell from `in` and needs `out` to hold the shell of its level");
     const fdtdx_geometry &g = ctx->g;
     // k steps of radius r need k*r planes of support on each side: ghost planes, or the global shell (r planes)
     const uint64_t reach = (uint64_t)nsteps * r;
     const uint64_t need_lo = g.ghost_lo ? reach : r, need_hi = g.ghost_hi ? reach : r;
     if ((g.ghost_lo && g.ghost_lo < reach) || (g.ghost_hi && g.ghost_hi < reach) || z_lo < need_lo || z_hi > g.local_planes - need_hi || z_lo > z_hi)
         return fail(FDTDX_ERR_INVALID, "fused plane range [%llu,%llu) needs %llu ghost planes towards a neighbour", (unsigned long long)z_lo, (unsigned long long)z_hi, (unsigned long long)reach);
-    return launch_tb(ctx, tb, po, pi, pm, prog, z_lo, z_hi, stream);
+    return launch_tb(ctx, tb, po, pi, pm, prog, z_lo, z_hi, stream, pe);
+}
+
+extern "C" int fdtdx_propagate_fused_planes(fdtdx_ctx *ctx, const char *out, const char *in, const char *mid, const fdtdx_program *prog,
+                                            uint32_t nsteps, uint64_t z_lo, uint64_t z_hi, void *stream)
+{
+    return fused_launch_checked(ctx, out, in, in, mid, prog, nsteps, z_lo, z_hi, stream);
+}
+
+extern "C" int fdtdx_propagate_fused_shells(fdtdx_ctx *ctx, const char *out, const char *in, const char *shell_even, const char *shell_odd,
+                                            const fdtdx_program *prog, uint32_t nsteps, uint64_t z_lo, uint64_t z_hi, void *stream)
+{
+    return fused_launch_checked(ctx, out, in, shell_even, shell_odd, prog, nsteps, z_lo, z_hi, stream);
 }
 
 extern "C" int fdtdx_propagate2_planes(fdtdx_ctx *ctx, const char *out, const char *in, const char *mid, const fdtdx_program *prog,
@@ -738,9 +763,9 @@ extern "C" int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const f
     if (pa == pb) return fail(FDTDX_ERR_INVALID, "sweep needs two different cubes");
     const fdtdx_geometry &g = ctx->g;
     const uint64_t lo = r, hi = g.local_planes - r;
-    // Level t lives in b for even t and in a for odd t (step 0 writes a = f(b)).  The last one to
-    // three steps are always single steps so that a and b end holding exactly the two newest
-    // levels, as after the reference's loop.
+    // Level t lives in b for even t and in a for odd t (step 0 writes a = f(b)), and so does its shell: even levels see b's
+    // shell, odd levels a's.  The last one to four steps are always single steps so that a and b end holding exactly the two
+    // newest levels, as after the reference's loop.
     const int want = (int)ctx->opt_temporal;  // 0 off, 1 auto (deepest), 2 / 3 steps per launch
     const TbVariantInfo *tb = nullptr;
     if (steps >= 4 && want != 0) {
@@ -758,6 +783,19 @@ extern "C" int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const f
             rc = launch_tb(ctx, tb, out, in, out, prog, lo, hi, stream);
             if (rc) return rc;
             done += 3;
+        }
+    } else if (tb && tb->shells) {
+        // Two steps per launch, in place between the two cubes: b -> a -> b ...  Every launch takes the even levels' shell
+        // from b and the odd levels' from a and writes interior cells only, so after the first hop a holds level 2 inside
+        // its own (odd) shell; the next hop reads that interior with b's shell in its place.  Hops come in pairs, so that
+        // the newest even level ends up in b, inside the shell that belongs to it.
+        const uint32_t hops = 2 * ((steps - 1) / 4);
+        for (uint32_t k = 0; k < hops; k++) {
+            float *out = (k % 2 == 0) ? pa : pb;
+            const float *in = (k % 2 == 0) ? pb : pa;
+            rc = launch_tb(ctx, tb, out, in, pa, prog, lo, hi, stream, pb);
+            if (rc) return rc;
+            done += 2;
         }
     } else if (tb) {
         // Two steps per launch hop between b and a third cube c that carries b's shell; a only

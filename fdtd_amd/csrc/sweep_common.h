@@ -12,7 +12,9 @@ enum : int {
     ORD_JACOBI_CHAIN = 2,  // jacobi.cu:31-38 with FMA contraction
     ORD_JACOBI_GOLDEN = 3, // jacobi.cu:478-485, separate mul/add
     ORD_COMP_CHAIN = 4,    // main.cu:104-118 device lambda: float constants, FMA contraction
-    ORD_COMP_GOLDEN = 5    // main.cu:55-72 host loop: double constants, evaluated in double, rounded once
+    ORD_COMP_GOLDEN = 5,   // main.cu:55-72 host loop: double constants, evaluated in double, rounded once
+    ORD_SPC_CHAIN = 6,     // fdtdspc.cu:66-72 device lambda with FMA contraction (fused kernels' registry only)
+    ORD_SPC_GOLDEN = 7     // fdtdspc.cu:46-52 host loop
 };
 constexpr bool is_composite(int order) { return order == ORD_COMP_CHAIN || order == ORD_COMP_GOLDEN; }
 
@@ -92,6 +94,12 @@ __device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned voff,
     f[2] = c;
     f[3] = d;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f), r, voff, 0, FDTDX_STORE_AUX);
+}
+
+// one cell (partially stored quads: the cells of a quad that are not shell cells)
+__device__ __forceinline__ void buf_st1(__amdgpu_buffer_rsrc_t r, unsigned voff, float a)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, a), r, voff, 0, FDTDX_STORE_AUX);
 }
 
 // Workgroups are dealt round-robin over the 8 XCDs (each with a private L2): hardware block b and

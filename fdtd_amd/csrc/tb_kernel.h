@@ -38,6 +38,7 @@ namespace fdtdx {
 struct TbParams {
     const float *in;   // level 0: full cube
     const float *mid;  // shell source for level 1 (interior values are ignored)
+    const float *even; // shell source for level 0 where it is not `in` itself (kernels with TbVariantInfo::shells only)
     float *out;        // level 2: interior written, shell untouched
     long long plane;
     int px, pxq, nx, ny;
@@ -48,7 +49,7 @@ struct TbParams {
     int gx, gy, gz;    // x tiles, y tiles, z chunks (1-D launch of gx*gy*gz workgroups)
     int qstep, qbase;  // x tile bx loads quads [qbase + bx*qstep, +64*RX); one tile: qbase 0, else -1 (see kernel)
     int xt;            // rows are cut into x tiles (possibly launched separately): a tile does not store its two outermost quads
-    float c[7];
+    float c[13];
 };
 
 __device__ __forceinline__ float dpp_from_prev_lane(float v)  // lane l receives lane l-1 (lane 0: lane 63)
@@ -238,6 +239,23 @@ __global__ __launch_bounds__(NW * 64) void tb_r1_kernel(const TbParams p)
         // ---- levels 1..KT: level l at plane pz-l from level l-1 planes pz-l-1, pz-l, pz-l+1 ------
 #pragma unroll
         for (int l = 1; l <= KT; l++) {
+            if (l == KT) {
+                // Loads for the next iteration, as soon as the lower levels have used the oldest input plane (level 2 takes
+                // its shell cells from it) and level 1 its shell source:
+                // input plane pz+1 into the dead slot, shell source of level-1 plane pz.  With three levels they are issued
+                // ahead of the last level's arithmetic and of the iteration's stores, so that the wait for them at the top
+                // of the next iteration does not wait for the stores as well.
+                const __amdgpu_buffer_rsrc_t rn = in_rsrc((pz + 1 < pend) ? pz + 1 : -1);
+                const bool zshn = zshell(pz);
+                const __amdgpu_buffer_rsrc_t rm = mid_rsrc((pz + 1 < pend) ? pz : -1);
+#pragma unroll
+                for (int j = 0; j < RY; j++)
+#pragma unroll
+                    for (int i = 0; i < RX; i++) {
+                        if constexpr (KT == 3) q[0][OLD][j][i] = buf_ld4(rn, goff[j][i]);
+                        mv[j][i] = buf_ld4(rm, zshn ? goff[j][i] : moff[j][i]);
+                    }
+            }
             // Rows closer than l to the tile's edge have no valid level-l value (the neighbouring tile
             // computes them): a wave all of whose rows are such rows skips the level.  What it leaves in
             // its queue and publishes is only ever read for rows that are invalid one level up.
@@ -281,18 +299,12 @@ __global__ __launch_bounds__(NW * 64) void tb_r1_kernel(const TbParams p)
                     }
             }
         }
-        // ---- loads for the next iteration: input plane pz+1 into the dead slot, shell source of plane pz
-        {
+        if constexpr (KT == 2) {  // two levels: the store above takes its shell cells from the slot the next input plane goes into
             const __amdgpu_buffer_rsrc_t rn = in_rsrc((pz + 1 < pend) ? pz + 1 : -1);
-            const bool zshn = zshell(pz);
-            const __amdgpu_buffer_rsrc_t rm = mid_rsrc((pz + 1 < pend) ? pz : -1);
 #pragma unroll
             for (int j = 0; j < RY; j++)
 #pragma unroll
-                for (int i = 0; i < RX; i++) {
-                    q[0][OLD][j][i] = buf_ld4(rn, goff[j][i]);
-                    mv[j][i] = buf_ld4(rm, zshn ? goff[j][i] : moff[j][i]);
-                }
+                for (int i = 0; i < RX; i++) q[0][OLD][j][i] = buf_ld4(rn, goff[j][i]);
         }
         if constexpr (PAR == 2)
             par ^= 1;
@@ -313,6 +325,7 @@ struct TbVariantInfo {
     int kt;     // fused steps per launch
     int radius; // 1 (tb_r1_kernel) or 2..4 (tb_rm_kernel)
     int nw, ry, rx, threads, lds_bytes;
+    int shells = 0;  // 1: honours TbParams::even and never writes a shell cell of `out` (in-place loops over two cubes)
     void (*launch)(const TbParams &, dim3 grid, hipStream_t);
 };
 int num_tb_variants();

@@ -124,6 +124,13 @@ class Stencil:
                                                         ctypes.byref(program), nsteps, z_lo, z_hi,
                                                         ctypes.c_void_p(stream or 0)))
 
+    def propagateFusedShells(self, output, input, shell_even, shell_odd, program, nsteps, z_lo, z_hi, stream=None):
+        """propagateFusedPlanes with both shell sources named: even levels (the input included) take their shell
+        cells from `shell_even`, odd levels from `shell_odd`; the shell of `output` is never written."""
+        _lib.check(self._L.fdtdx_propagate_fused_shells(self._h, output.encode(), input.encode(), shell_even.encode(),
+                                                        shell_odd.encode(), ctypes.byref(program), nsteps, z_lo, z_hi,
+                                                        ctypes.c_void_p(stream or 0)))
+
     def sweep(self, a, b, program, steps, stream=None):
         """The drivers' whole time loop on one rank (fdtd1.cu:68-80)."""
         _lib.check(self._L.fdtdx_sweep(self._h, a.encode(), b.encode(), ctypes.byref(program), steps,

@@ -152,12 +152,23 @@ int fdtdx_propagate_ptr(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
  * from `mid` (the cube a single step from `in` would have written), those of the skipped even
  * level from `in`.  `out` must already hold the shell of its level: that of `in` for nsteps = 2
  * (out != mid), that of `mid` for nsteps = 3 (out may be `mid` itself: the launch reads only its
- * shell cells and writes only interior cells).  Device order only; radius-1 programs (star, jacobi)
- * with nsteps 2 or 3, the radius-2 star with nsteps 2 (FDTDX_ERR_UNSUPPORTED otherwise).  Towards a
+ * shell cells and writes only interior cells).  Radius-1 programs (star, jacobi) with nsteps 2 or 3,
+ * the radius-2 star and the 13-point program with nsteps 2 (FDTDX_ERR_UNSUPPORTED otherwise).  Towards a
  * neighbouring slab the range needs nsteps x radius ghost planes (create the context with M that large). */
 int fdtdx_propagate_fused_planes(fdtdx_ctx *ctx, const char *out, const char *in, const char *mid,
                                  const fdtdx_program *prog, uint32_t nsteps, uint64_t z_lo, uint64_t z_hi,
                                  void *stream);
+/* The same launch with both shell sources named: cells of the global shell are taken from `shell_even` for the even
+ * levels of the launch (level 0, the input, included: `in` is read for its interior cells only where `shell_even` is
+ * another cube) and from `shell_odd` for the odd ones; the shell of `out` is never written, whatever it holds.  This is
+ * what lets a two-step loop run in place between the reference's two cubes (fdtd1.cu:68-80 keeps level t in one cube for
+ * even t, in the other for odd t, shells included): out = a, in = b, then out = b, in = a, always with shell_even = b and
+ * shell_odd = a; after an even number of launches b holds the newest even level inside its own shell.  No third cube.
+ * FDTDX_ERR_UNSUPPORTED for the fused kernels that only take their even shell from `in` (radius-1 and radius-2 stars with
+ * nsteps = 2 need out != shell_odd and shell_even == in). */
+int fdtdx_propagate_fused_shells(fdtdx_ctx *ctx, const char *out, const char *in, const char *shell_even,
+                                 const char *shell_odd, const fdtdx_program *prog, uint32_t nsteps, uint64_t z_lo,
+                                 uint64_t z_hi, void *stream);
 /* nsteps = 2 */
 int fdtdx_propagate2_planes(fdtdx_ctx *ctx, const char *out, const char *in, const char *mid,
                             const fdtdx_program *prog, uint64_t z_lo, uint64_t z_hi, void *stream);

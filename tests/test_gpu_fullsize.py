@@ -39,7 +39,7 @@ def gpu_run(kind, M, a, b, steps):
                                            ("star", 3, 2), ("star", 5, 2), ("star", 6, 2), ("star", 7, 2),
                                            # four steps and more run through the fused kernels (three steps per launch at
                                            # radius 1, two at radius 2) and finish with single steps
-                                           ("star", 1, 7), ("jacobi7", 1, 8), ("star", 2, 6)])
+                                           ("star", 1, 7), ("jacobi7", 1, 8), ("star", 2, 6), ("spc13", 1, 9)])
 def test_fullsize_vs_oracle(oracle_cpu, kind, M, steps):
     if kind == "jacobi7":
         a = oracle_cpu.init_jacobi(N, N, N)

@@ -5,12 +5,12 @@ cubes whose two shells differ (the drivers' p0/p1 are independent random fields,
 import numpy as np
 import pytest
 
-from fdtd_amd import Stencil, make_program
+from fdtd_amd import Stencil, make_program, ORDER_CHAIN, ORDER_GOLDEN
 
 pytestmark = pytest.mark.gpu
 
 
-def run(cpu, kind, shape, steps, tb_variant=-1, tb_zchunks=0, temporal=1, M=1):
+def run(cpu, kind, shape, steps, tb_variant=-1, tb_zchunks=0, temporal=1, M=1, golden=False):
     Z, Y, X = shape
     if kind == "jacobi7":
         a = cpu.init_jacobi(Z, Y, X)
@@ -18,7 +18,7 @@ def run(cpu, kind, shape, steps, tb_variant=-1, tb_zchunks=0, temporal=1, M=1):
     else:
         a, b = cpu.init_mt(Z, Y, X)
     ca, cb = a.copy(), b.copy()
-    cpu.run(kind, ca, cb, steps, M=M, order=cpu.ORDER_CHAIN)
+    cpu.run(kind, ca, cb, steps, M=M, order=cpu.ORDER_GOLDEN if golden else cpu.ORDER_CHAIN)
     with Stencil(Z, Y, X, M) as st:
         st.mallocCube("p0")
         st.mallocCube("p1")
@@ -27,7 +27,7 @@ def run(cpu, kind, shape, steps, tb_variant=-1, tb_zchunks=0, temporal=1, M=1):
         st.setOption("temporal", temporal)
         st.setOption("tb_variant", tb_variant)
         st.setOption("tb_zchunks", tb_zchunks)
-        st.sweep("p0", "p1", make_program(kind, radius=M), steps)
+        st.sweep("p0", "p1", make_program(kind, radius=M, order=ORDER_GOLDEN if golden else ORDER_CHAIN), steps)
         st.sync()
         ga, gb = np.empty_like(a), np.empty_like(b)
         st.transferCubeToCPU(ga, "p0")
@@ -83,6 +83,22 @@ def test_fused_radius2_step_counts(oracle_cpu, steps):
                                    (9, 30, 1531)])
 def test_fused_radius2_small_ragged_wide(oracle_cpu, shape):
     run(oracle_cpu, "star", shape, 7, M=2)
+
+
+@pytest.mark.parametrize("golden", [False, True], ids=["device-order", "golden-order"])
+@pytest.mark.parametrize("steps", [4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
+def test_fused_spc13_step_counts(oracle_cpu, steps, golden):
+    """fdtdspc's update fused two steps per launch (tbs_kernel.h), in place between the two cubes (hops b -> a -> b with
+    the level-0 shell patched in on every second hop): several y tiles and z chunks, ragged x, every residue of the
+    step count, both arithmetic orders."""
+    info = run(oracle_cpu, "spc13", (17, 61, 509), steps, tb_zchunks=2, golden=golden)
+    assert ("fused2" in info) == (steps >= 5)
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 3), (5, 7, 9), (9, 20, 21), (40, 19, 300), (9, 130, 64), (31, 9, 40), (9, 30, 513), (9, 30, 1024),
+                                   (9, 30, 1531), (64, 40, 512), (9, 20, 257), (9, 20, 260), (9, 20, 261), (9, 20, 256), (9, 20, 253)])
+def test_fused_spc13_small_ragged_wide(oracle_cpu, shape):
+    run(oracle_cpu, "spc13", shape, 9)
 
 
 def test_temporal_off_equals_on(oracle_cpu):
