@@ -61,11 +61,11 @@ __device__ __forceinline__ float dpp_from_next_lane(float v)  // lane l receives
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x134, 0xF, 0xF, false));
 }
 
-// one cell: the reference's summation order with every "+ c*v" fused (device order)
+// one cell, in one of the reference's four summation orders
 template <int ORDER>
 __device__ __forceinline__ float cell7(const float (&c)[7], float C, float xp, float xm, float yp, float ym, float zp, float zm)
 {
-    if constexpr (ORDER == ORD_STAR_CHAIN) {  // fdtd1.cu:63
+    if constexpr (ORDER == ORD_STAR_CHAIN) {  // fdtd1.cu:63, every "+ c*v" one FMA
         float a = c[0] * C;
         a = __builtin_fmaf(c[1], xp, a);
         a = __builtin_fmaf(c[2], xm, a);
@@ -73,7 +73,12 @@ __device__ __forceinline__ float cell7(const float (&c)[7], float C, float xp, f
         a = __builtin_fmaf(c[4], ym, a);
         a = __builtin_fmaf(c[5], zp, a);
         return __builtin_fmaf(c[6], zm, a);
-    } else {  // jacobi.cu:31-38: ce*E + cw*W + cs*S + cn*N + ct*T + cb*B + cc*C
+    } else if constexpr (ORDER == ORD_STAR_GOLDEN) {  // fdtd1.cu:46-49: centre + parenthesised pairs, separate multiplies and adds
+        float a = c[0] * C;
+        a = a + (c[1] * xp + c[2] * xm);
+        a = a + (c[3] * yp + c[4] * ym);
+        return a + (c[5] * zp + c[6] * zm);
+    } else if constexpr (ORDER == ORD_JACOBI_CHAIN) {  // jacobi.cu:31-38: ce*E + cw*W + cs*S + cn*N + ct*T + cb*B + cc*C, fused
         float a = c[1] * xp;
         a = __builtin_fmaf(c[2], xm, a);
         a = __builtin_fmaf(c[3], yp, a);
@@ -81,6 +86,9 @@ __device__ __forceinline__ float cell7(const float (&c)[7], float C, float xp, f
         a = __builtin_fmaf(c[5], zp, a);
         a = __builtin_fmaf(c[6], zm, a);
         return __builtin_fmaf(c[0], C, a);
+    } else {  // jacobi.cu:478-485: the same sum with separate multiplies and adds
+        static_assert(ORDER == ORD_JACOBI_GOLDEN, "unknown order");
+        return c[1] * xp + c[2] * xm + c[3] * yp + c[4] * ym + c[5] * zp + c[6] * zm + c[0] * C;
     }
 }
 
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(NW * 64) void tb_r1_kernel(const TbParams p)
 }
 
 struct TbVariantInfo {
-    int order;  // ORD_STAR_CHAIN | ORD_JACOBI_CHAIN
+    int order;  // ORD_STAR_* | ORD_JACOBI_* | ORD_SPC_*
     int kt;     // fused steps per launch
     int radius; // 1 (tb_r1_kernel) or 2..4 (tb_rm_kernel)
     int nw, ry, rx, threads, lds_bytes;

@@ -11,7 +11,7 @@
 // Fixed shell (M cells wide, fdtd2.cu:43-45 leaves it untouched in both cubes): level-1 shell cells come
 // from `mid` (the cube a single step from `in` would write), level-2 shell components of partially
 // stored quads from `in`, whose shell `out` must already carry.  With that a launch is bit-identical
-// to two single steps in the device order (fdtd2.cu:66-69).
+// to two single steps, in the device order (fdtd2.cu:66-69) or the host order (fdtd2.cu:46-52).
 #pragma once
 #include "tb_kernel.h"
 
@@ -20,7 +20,7 @@ namespace fdtdx {
 // One time level of one plane for the RY rows of a wave.  q[(KC + r) % QN] = plane z+r, q[(KC - r + QN) % QN] =
 // plane z-r (slots rotate by renaming).  Row j's y neighbours at distance r are rows of the same wave
 // (registers) or rows of the waves above/below (LDS image `exl` of this level: [wave][row][quad column][lane]).
-template <int M, int NW, int RY, int RX, int KC>
+template <int M, int NW, int RY, int RX, int KC, int GOLDEN>
 __device__ __forceinline__ void star_rows(float4 (&res)[RY][RX], const float4 (&q)[2 * M + 1][RY][RX], const float4 (*exl)[RY][RX][64],
                                           const float (&c)[7], int w, int lane)
 {
@@ -65,13 +65,19 @@ __device__ __forceinline__ void star_rows(float4 (&res)[RY][RX], const float4 (&
                 const float yp[4] = {Yp.x, Yp.y, Yp.z, Yp.w}, ym[4] = {Ym.x, Ym.y, Ym.z, Ym.w};
                 const float zp[4] = {Zp.x, Zp.y, Zp.z, Zp.w}, zm[4] = {Zm.x, Zm.y, Zm.z, Zm.w};
 #pragma unroll
-                for (int k = 0; k < 4; k++) {  // fdtd2.cu:66-69: x+r, x-r, y+r, y-r, z+r, z-r, every "+ c*v" fused
-                    a[k] = __builtin_fmaf(c[1], xs[M + k + r], a[k]);
-                    a[k] = __builtin_fmaf(c[2], xs[M + k - r], a[k]);
-                    a[k] = __builtin_fmaf(c[3], yp[k], a[k]);
-                    a[k] = __builtin_fmaf(c[4], ym[k], a[k]);
-                    a[k] = __builtin_fmaf(c[5], zp[k], a[k]);
-                    a[k] = __builtin_fmaf(c[6], zm[k], a[k]);
+                for (int k = 0; k < 4; k++) {
+                    if constexpr (GOLDEN) {  // fdtd2.cu:46-52: (+r, -r) pairs, separate multiplies and adds
+                        a[k] = a[k] + (c[1] * xs[M + k + r] + c[2] * xs[M + k - r]);
+                        a[k] = a[k] + (c[3] * yp[k] + c[4] * ym[k]);
+                        a[k] = a[k] + (c[5] * zp[k] + c[6] * zm[k]);
+                    } else {  // fdtd2.cu:66-69: x+r, x-r, y+r, y-r, z+r, z-r, every "+ c*v" fused
+                        a[k] = __builtin_fmaf(c[1], xs[M + k + r], a[k]);
+                        a[k] = __builtin_fmaf(c[2], xs[M + k - r], a[k]);
+                        a[k] = __builtin_fmaf(c[3], yp[k], a[k]);
+                        a[k] = __builtin_fmaf(c[4], ym[k], a[k]);
+                        a[k] = __builtin_fmaf(c[5], zp[k], a[k]);
+                        a[k] = __builtin_fmaf(c[6], zm[k], a[k]);
+                    }
                 }
             }
             res[j][i] = make_float4(a[0], a[1], a[2], a[3]);
@@ -79,7 +85,7 @@ __device__ __forceinline__ void star_rows(float4 (&res)[RY][RX], const float4 (&
     }
 }
 
-template <int M, int NW, int RY, int RX>
+template <int M, int NW, int RY, int RX, int GOLDEN>
 __global__ __launch_bounds__(NW * 64) void tb_rm_kernel(const TbParams p)
 {
     static_assert(M >= 2 && M <= 4, "x neighbours must lie in the adjacent quad");
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(NW * 64) void tb_rm_kernel(const TbParams p)
         __syncthreads();
         float4 res[RY][RX];
         if (has1) {  // uniform
-            star_rows<M, NW, RY, RX, SLOT(M)>(res, q0, ex[par][0], c, w, lane);
+            star_rows<M, NW, RY, RX, SLOT(M), GOLDEN>(res, q0, ex[par][0], c, w, lane);
             const bool zsh = zshell(pz - M);
 #pragma unroll
             for (int j = 0; j < RY; j++)
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(NW * 64) void tb_rm_kernel(const TbParams p)
                 }
         }
         if (has2) {
-            star_rows<M, NW, RY, RX, SLOT(M + 1)>(res, q1, ex[par][1], c, w, lane);
+            star_rows<M, NW, RY, RX, SLOT(M + 1), GOLDEN>(res, q1, ex[par][1], c, w, lane);
             const bool st = (pz - 2 * M >= zs) && (pz - 2 * M < ze);
             const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.out + (long long)(pz - 2 * M) * p.plane, st ? plane_bytes : 0u);
 #pragma unroll
@@ -240,18 +246,18 @@ __global__ __launch_bounds__(NW * 64) void tb_rm_kernel(const TbParams p)
     }
 }
 
-template <int M, int NW, int RY, int RX>
+template <int M, int NW, int RY, int RX, int GOLDEN>
 void tbm_launch(const TbParams &p, dim3 grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((tb_rm_kernel<M, NW, RY, RX>), grid, dim3(NW * 64), 0, s, p);
+    hipLaunchKernelGGL((tb_rm_kernel<M, NW, RY, RX, GOLDEN>), grid, dim3(NW * 64), 0, s, p);
 }
 
-template <int M, int NW, int RY, int RX>
+template <int M, int NW, int RY, int RX, int GOLDEN>
 struct TbmRegistrar {
     TbmRegistrar()
     {
         TbVariantInfo v;
-        v.order = ORD_STAR_CHAIN;
+        v.order = GOLDEN ? ORD_STAR_GOLDEN : ORD_STAR_CHAIN;
         v.radius = M;
         v.kt = 2;
         v.nw = NW;
@@ -259,10 +265,10 @@ struct TbmRegistrar {
         v.rx = RX;
         v.threads = NW * 64;
         v.lds_bytes = 2 * 2 * NW * RY * RX * 64 * 16;
-        v.launch = &tbm_launch<M, NW, RY, RX>;
+        v.launch = &tbm_launch<M, NW, RY, RX, GOLDEN>;
         register_tb_variant(v);
     }
 };
-#define FDTDX_TBM_VARIANT(M, NW, RY, RX) static ::fdtdx::TbmRegistrar<M, NW, RY, RX> tbmreg_##M##_##NW##_##RY##_##RX;
+#define FDTDX_TBM_VARIANT(M, NW, RY, RX, GOLDEN) static ::fdtdx::TbmRegistrar<M, NW, RY, RX, GOLDEN> tbmreg_##M##_##NW##_##RY##_##RX##_##GOLDEN;
 
 }  // namespace fdtdx

@@ -100,8 +100,8 @@ class HipSlabBackend:
 
     def can_fuse(self, program):
         """Deepest fusion the library has a kernel for (0: none)."""
-        if program.order != _lib.ORDER_CHAIN or program.kind not in (_lib.STAR, _lib.JACOBI7):
-            return 0
+        if program.kind == _lib.SPC13:
+            return 2  # tbs_kernel.h: two steps
         radius = program.radius if program.kind == _lib.STAR else 1
         return {1: 3, 2: 2}.get(radius, 0)  # tb_kernel.h: radius 1, two or three steps; tbm_kernel.h: radius 2, two steps
 

@@ -46,6 +46,20 @@ def test_fused_step_counts(oracle_cpu, kt, kind, steps):
     assert f"fused{kt}" in info
 
 
+@pytest.mark.parametrize("steps", [4, 7, 9, 10, 11])
+@pytest.mark.parametrize("kind,M,kt", [("star", 1, 3), ("star", 1, 2), ("jacobi7", 1, 3), ("jacobi7", 1, 2), ("star", 2, 2)])
+def test_fused_host_order(oracle_cpu, kind, M, kt, steps):
+    """The fused kernels in the host loops' order (fdtd1.cu:46-49, fdtd2.cu:46-52, jacobi.cu:478-485: separate IEEE
+    multiplies and adds), the order the reference's compiled loops pin: equal to the oracle's golden-order loop bit for bit."""
+    info = run(oracle_cpu, kind, (13, 61, 509) if M == 1 else (17, 61, 509), steps, tb_zchunks=2, temporal=kt if M == 1 else 1, M=M, golden=True)
+    assert f"fused{kt}" in info
+
+
+def test_host_order_wide_rows(oracle_cpu):
+    for kind, M in (("star", 1), ("jacobi7", 1), ("star", 2)):
+        assert "fused" in run(oracle_cpu, kind, (9, 30, 1024), 7, M=M, golden=True)
+
+
 def test_auto_fuses_three_steps(oracle_cpu):
     assert "fused3" in run(oracle_cpu, "star", (13, 61, 509), 10)
 
