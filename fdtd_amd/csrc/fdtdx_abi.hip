@@ -5,7 +5,7 @@
 // to process communication is NOT in here (the reference calls MPI at stencil.h:639-656): this
 // library exposes the contiguous ghost/boundary plane regions (fdtdx_halo_region) and the
 // caller moves them with RCCL send/recv (fdtd_amd/slab.py) while the interior sweep runs.
-#include "../../include/fdtdx.h"
+#include "fdtdx_ctx.h"
 #include "sweep_common.h"
 #include "tb_kernel.h"
 #include "yee_kernel.h"
@@ -56,7 +56,7 @@ using namespace fdtdx;
 // ---- error reporting -----------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char *fmt, ...)
+int fdtdx_fail(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -65,51 +65,7 @@ static int fail(int code, const char *fmt, ...)
     return code;
 }
 
-#define HIP_TRY(expr)                                                                         \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess) return fail(FDTDX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
-
-struct Cube {
-    float *ptr = nullptr;
-    bool owned = false;
-};
-
-struct fdtdx_ctx {
-    fdtdx_config cfg;
-    fdtdx_geometry g;
-    int device = 0;
-    std::map<std::string, Cube> pool;  // memoryPool of stencil.h:361
-    struct AddrList {
-        uint64_t *ptr = nullptr;
-        size_t capacity = 0, count = 0;
-    };
-    std::map<std::string, AddrList> addr;  // address lists (stencil.h:363: addrLen)
-    int64_t opt_zchunks = 0;           // 0 = auto
-    int64_t opt_variant = -1;          // -1 = auto
-    int64_t opt_temporal = 1;          // fuse two steps per launch where a fused kernel exists
-    int64_t opt_tb_variant = -1;       // shape of the fused kernel, -1 = auto
-    int64_t opt_tb_zchunks = 0;
-    float *tb_scratch = nullptr;       // third cube of the fused time loop (owned)
-    float *saved_sum = nullptr;        // fdtdx_composite_step: sum values at the injection addresses
-    size_t saved_cap = 0;
-    float *static_scratch = nullptr;   // device address of the file-scope `scratch` array on ctx->device
-    uint64_t launches = 0;             // sweep launches issued so far (bench bookkeeping)
-    char last_launch[256] = "";
-    char last_fused[256] = "";         // last fused (two-step) launch, "" if none since creation
-};
-
 extern "C" const char *fdtdx_last_error(void) { return g_err; }
-
-// Every entry point that touches the GPU first makes the context's device current, so that several
-// contexts in one process (one per GPU, or a thread whose current device is another one) reach the right
-// card.  (The reference never selects a device: one rank sees one GPU, run.sh:20.)
-#define USE_DEVICE(ctx)                                              \
-    do {                                                             \
-        if (!(ctx)) return fail(FDTDX_ERR_INVALID, "null context");  \
-        HIP_TRY(hipSetDevice((ctx)->device));                        \
-    } while (0)
 
 // ---- decomposition (stencil.h:398-412) ---------------------------------------------------------
 extern "C" int fdtdx_decompose(const fdtdx_config *cfg, fdtdx_geometry *out)
@@ -210,6 +166,7 @@ extern "C" int fdtdx_destroy(fdtdx_ctx *ctx)
         if (kv.second.owned && kv.second.ptr && hipFree(kv.second.ptr) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(%s) failed", kv.first.c_str());
     if (ctx->tb_scratch && hipFree(ctx->tb_scratch) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(scratch) failed");
     if (ctx->saved_sum && hipFree(ctx->saved_sum) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(saved) failed");
+    fdtdx_comm_release(ctx);
     for (auto &kv : ctx->addr)
         if (kv.second.ptr && hipFree(kv.second.ptr) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(%s) failed", kv.first.c_str());
     delete ctx;
@@ -279,7 +236,7 @@ extern "C" int fdtdx_free(fdtdx_ctx *ctx, const char *name)
     return FDTDX_OK;
 }
 
-static int find_cube(fdtdx_ctx *ctx, const char *name, float **p)
+int fdtdx_find_cube(fdtdx_ctx *ctx, const char *name, float **p)
 {
     if (!ctx || !name) return fail(FDTDX_ERR_INVALID, "null argument");
     auto it = ctx->pool.find(name);
@@ -291,7 +248,7 @@ static int find_cube(fdtdx_ctx *ctx, const char *name, float **p)
 extern "C" int fdtdx_get_cube(fdtdx_ctx *ctx, const char *name, float **device_ptr)
 {
     if (!device_ptr) return fail(FDTDX_ERR_INVALID, "null argument");
-    return find_cube(ctx, name, device_ptr);
+    return fdtdx_find_cube(ctx, name, device_ptr);
 }
 
 // ---- transfers (stencil.h:596-637): pitch conversion done by the copy engine -------------------
@@ -318,7 +275,7 @@ static int copy_planes_d2h(fdtdx_ctx *ctx, float *host, const float *dev, uint64
 extern "C" int fdtdx_transfer_cube_to_gpu(fdtdx_ctx *ctx, const char *name, const float *host)
 {
     float *d;
-    int rc = find_cube(ctx, name, &d);
+    int rc = fdtdx_find_cube(ctx, name, &d);
     if (rc) return rc;
     if (!host) return fail(FDTDX_ERR_INVALID, "null host pointer");
     const fdtdx_geometry &g = ctx->g;
@@ -328,7 +285,7 @@ extern "C" int fdtdx_transfer_cube_to_gpu(fdtdx_ctx *ctx, const char *name, cons
 extern "C" int fdtdx_upload_local(fdtdx_ctx *ctx, const char *name, const float *host_local)
 {
     float *d;
-    int rc = find_cube(ctx, name, &d);
+    int rc = fdtdx_find_cube(ctx, name, &d);
     if (rc) return rc;
     if (!host_local) return fail(FDTDX_ERR_INVALID, "null host pointer");
     return copy_planes_h2d(ctx, d, host_local, ctx->g.local_planes);
@@ -337,7 +294,7 @@ extern "C" int fdtdx_upload_local(fdtdx_ctx *ctx, const char *name, const float 
 extern "C" int fdtdx_transfer_cube_to_cpu(fdtdx_ctx *ctx, float *host, const char *name)
 {
     float *d;
-    int rc = find_cube(ctx, name, &d);
+    int rc = fdtdx_find_cube(ctx, name, &d);
     if (rc) return rc;
     if (!host) return fail(FDTDX_ERR_INVALID, "null host pointer");
     const fdtdx_geometry &g = ctx->g;
@@ -347,7 +304,7 @@ extern "C" int fdtdx_transfer_cube_to_cpu(fdtdx_ctx *ctx, float *host, const cha
 extern "C" int fdtdx_download_owned(fdtdx_ctx *ctx, float *host_owned, const char *name)
 {
     float *d;
-    int rc = find_cube(ctx, name, &d);
+    int rc = fdtdx_find_cube(ctx, name, &d);
     if (rc) return rc;
     if (!host_owned) return fail(FDTDX_ERR_INVALID, "null host pointer");
     const fdtdx_geometry &g = ctx->g;
@@ -358,9 +315,9 @@ extern "C" int fdtdx_download_owned(fdtdx_ctx *ctx, float *host_owned, const cha
 extern "C" int fdtdx_init_mt(fdtdx_ctx *ctx, const char *name_p0, const char *name_p1)
 {
     float *d0, *d1;
-    int rc = find_cube(ctx, name_p0, &d0);
+    int rc = fdtdx_find_cube(ctx, name_p0, &d0);
     if (rc) return rc;
-    rc = find_cube(ctx, name_p1, &d1);
+    rc = fdtdx_find_cube(ctx, name_p1, &d1);
     if (rc) return rc;
     USE_DEVICE(ctx);
     const fdtdx_geometry &g = ctx->g;
@@ -396,7 +353,7 @@ extern "C" int fdtdx_init_mt(fdtdx_ctx *ctx, const char *name_p0, const char *na
 extern "C" int fdtdx_init_jacobi(fdtdx_ctx *ctx, const char *name)
 {
     float *d;
-    int rc = find_cube(ctx, name, &d);
+    int rc = fdtdx_find_cube(ctx, name, &d);
     if (rc) return rc;
     USE_DEVICE(ctx);
     const fdtdx_geometry &g = ctx->g;
@@ -542,7 +499,8 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
         // to fill its queue, so split z only as far as needed to cover the chip, and keep the
         // fill below ~1/6 of a chunk
         const long long tiles = (long long)gx * gy;
-        chunks = std::max<long long>(1, 256 / tiles);  // never more workgroups than CUs: a second round would run nearly empty
+        const long long cus = std::max<long long>(1, 256 - ctx->opt_reserve_cus);
+        chunks = std::max<long long>(1, cus / tiles);  // never more workgroups than CUs: a second round would run nearly empty
         if (threads <= 256) chunks *= 2;  // small workgroups: two per CU
         const long long min_len = std::max<long long>(12LL * r, 16);
         chunks = std::min(chunks, std::max<long long>(1, nz / min_len));
@@ -570,9 +528,9 @@ extern "C" int fdtdx_propagate_ptr(fdtdx_ctx *ctx, float *out, const float *in, 
 extern "C" int fdtdx_propagate_planes(fdtdx_ctx *ctx, const char *out, const char *in, const fdtdx_program *prog, uint64_t z_lo, uint64_t z_hi, void *stream)
 {
     float *po, *pi;
-    int rc = find_cube(ctx, out, &po);
+    int rc = fdtdx_find_cube(ctx, out, &po);
     if (rc) return rc;
-    rc = find_cube(ctx, in, &pi);
+    rc = fdtdx_find_cube(ctx, in, &pi);
     if (rc) return rc;
     return launch_sweep(ctx, po, pi, prog, z_lo, z_hi, stream);
 }
@@ -669,11 +627,12 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
             // launch reaches beyond its range are re-read, plus start-up: about 6 planes' worth in all, from
             // timings at 512^3 and 1024^3): take the chunk count with the best product of the two efficiencies.
             const long long tiles = (long long)q.gx * q.gy;
+            const long long cus = std::max<long long>(1, 256 - ctx->opt_reserve_cus);
             double best = -1.0;
             chunks = 1;
             for (long long cnt = 1; cnt <= std::max<long long>(1, nz / 16) && cnt * tiles <= 4096; cnt++) {
                 const long long len = (nz + cnt - 1) / cnt, n = tiles * ((nz + len - 1) / len);
-                const double eff = (double)n / (double)((n + 255) / 256 * 256) * (double)len / (double)(len + 4 + reach);
+                const double eff = (double)n / (double)((n + cus - 1) / cus * cus) * (double)len / (double)(len + 4 + reach);
                 if (eff > best + 1e-9) best = eff, chunks = cnt;
             }
         }
@@ -711,7 +670,7 @@ static int fused_launch_checked(fdtdx_ctx *ctx, const char *out, const char *in,
     if (rc) return rc;
     if (nsteps != 2 && nsteps != 3) return fail(FDTDX_ERR_UNSUPPORTED, "fused sweeps advance 2 or 3 steps, not %u", nsteps);
     float *po, *pi, *pe, *pm;
-    if ((rc = find_cube(ctx, out, &po)) || (rc = find_cube(ctx, in, &pi)) || (rc = find_cube(ctx, even, &pe)) || (rc = find_cube(ctx, odd, &pm)))
+    if ((rc = fdtdx_find_cube(ctx, out, &po)) || (rc = fdtdx_find_cube(ctx, in, &pi)) || (rc = fdtdx_find_cube(ctx, even, &pe)) || (rc = fdtdx_find_cube(ctx, odd, &pm)))
         return rc;
     const TbVariantInfo *tb = pick_tb(ctx, prog, (int)nsteps);
     if (!tb)
@@ -756,9 +715,9 @@ extern "C" int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const f
     int rc = check_program(ctx, prog, &r);
     if (rc) return rc;
     float *pa, *pb;
-    rc = find_cube(ctx, a, &pa);
+    rc = fdtdx_find_cube(ctx, a, &pa);
     if (rc) return rc;
-    rc = find_cube(ctx, b, &pb);
+    rc = fdtdx_find_cube(ctx, b, &pb);
     if (rc) return rc;
     if (pa == pb) return fail(FDTDX_ERR_INVALID, "sweep needs two different cubes");
     const fdtdx_geometry &g = ctx->g;
@@ -854,7 +813,7 @@ extern "C" int fdtdx_propagate_composite_planes(fdtdx_ctx *ctx, const char *out,
     if (!ctx || !comp) return fail(FDTDX_ERR_INVALID, "null argument");
     float *po, *pi, *pv;
     int rc;
-    if ((rc = find_cube(ctx, out, &po)) || (rc = find_cube(ctx, in, &pi)) || (rc = find_cube(ctx, vel, &pv))) return rc;
+    if ((rc = fdtdx_find_cube(ctx, out, &po)) || (rc = fdtdx_find_cube(ctx, in, &pi)) || (rc = fdtdx_find_cube(ctx, vel, &pv))) return rc;
     if (po == pv) return fail(FDTDX_ERR_INVALID, "the composite update cannot write its velocity cube");
     if (comp->scal_den == 0.0) return fail(FDTDX_ERR_INVALID, "scal_den is zero");
     return launch_sweep(ctx, po, pi, nullptr, z_lo, z_hi, stream, comp, pv);
@@ -924,7 +883,7 @@ __global__ void inject_planes_kernel(float *cube, const uint64_t *addr, uint64_t
 extern "C" int fdtdx_inject(fdtdx_ctx *ctx, const char *cube, const char *addr_name, float add, uint64_t z_lo, uint64_t z_hi, void *stream)
 {
     float *pc;
-    int rc = find_cube(ctx, cube, &pc);
+    int rc = fdtdx_find_cube(ctx, cube, &pc);
     if (rc) return rc;
     if (!addr_name) return fail(FDTDX_ERR_INVALID, "null argument");
     if ((rc = owned_range(ctx, z_lo, z_hi, "inject"))) return rc;
@@ -1020,7 +979,7 @@ extern "C" int fdtdx_filt_planes(fdtdx_ctx *ctx, const char *cube, int64_t zsel,
                                  uint64_t z_lo, uint64_t z_hi, void *stream)
 {
     float *pc;
-    int rc = find_cube(ctx, cube, &pc);
+    int rc = fdtdx_find_cube(ctx, cube, &pc);
     if (rc) return rc;
     if ((rc = owned_range(ctx, z_lo, z_hi, "filt"))) return rc;
     if (order != FDTDX_ORDER_CHAIN && order != FDTDX_ORDER_GOLDEN) return fail(FDTDX_ERR_INVALID, "unknown order %u", order);
@@ -1043,8 +1002,8 @@ static int composite_step_check(fdtdx_ctx *ctx, const char *out, const char *in,
 {
     if (!ctx || !comp || !addr_name) return fail(FDTDX_ERR_INVALID, "null argument");
     int rc;
-    if ((rc = find_cube(ctx, out, &a->po)) || (rc = find_cube(ctx, in, &a->pi)) || (rc = find_cube(ctx, vel, &a->pv)) ||
-        (rc = find_cube(ctx, sum, &a->ps)))
+    if ((rc = fdtdx_find_cube(ctx, out, &a->po)) || (rc = fdtdx_find_cube(ctx, in, &a->pi)) || (rc = fdtdx_find_cube(ctx, vel, &a->pv)) ||
+        (rc = fdtdx_find_cube(ctx, sum, &a->ps)))
         return rc;
     if (a->po == a->pv || a->ps == a->po || a->ps == a->pi || a->ps == a->pv || a->po == a->pi)
         return fail(FDTDX_ERR_INVALID, "composite step needs four different cubes");
@@ -1145,7 +1104,7 @@ extern "C" int fdtdx_mul_acc(fdtdx_ctx *ctx, const char *sum, const char *a, con
 {
     float *ps, *pa, *pb;
     int rc;
-    if ((rc = find_cube(ctx, sum, &ps)) || (rc = find_cube(ctx, a, &pa)) || (rc = find_cube(ctx, b, &pb))) return rc;
+    if ((rc = fdtdx_find_cube(ctx, sum, &ps)) || (rc = fdtdx_find_cube(ctx, a, &pa)) || (rc = fdtdx_find_cube(ctx, b, &pb))) return rc;
     if ((rc = owned_range(ctx, z_lo, z_hi, "mul_acc"))) return rc;
     if (order != FDTDX_ORDER_CHAIN && order != FDTDX_ORDER_GOLDEN) return fail(FDTDX_ERR_INVALID, "unknown order %u", order);
     const uint64_t X = ctx->cfg.X, Y = ctx->cfg.Y;
@@ -1176,7 +1135,7 @@ extern "C" int fdtdx_yee3d_half(fdtdx_ctx *ctx, const char *const fields[6], int
     YeeParams p;
     int rc;
     for (int i = 0; i < 6; i++) {
-        if ((rc = find_cube(ctx, fields[i], &p.f[i]))) return rc;
+        if ((rc = fdtdx_find_cube(ctx, fields[i], &p.f[i]))) return rc;
         for (int k = 0; k < i; k++)
             if (p.f[k] == p.f[i]) return fail(FDTDX_ERR_INVALID, "the six fields must be six different cubes");
     }
@@ -1223,7 +1182,7 @@ extern "C" int fdtdx_yee3d_step_fused(fdtdx_ctx *ctx, const char *const before[6
     float *f[12];
     int rc;
     for (int i = 0; i < 12; i++) {
-        if ((rc = find_cube(ctx, i < 6 ? before[i] : after[i - 6], &f[i]))) return rc;
+        if ((rc = fdtdx_find_cube(ctx, i < 6 ? before[i] : after[i - 6], &f[i]))) return rc;
         for (int k = 0; k < i; k++)
             if (f[k] == f[i]) return fail(FDTDX_ERR_INVALID, "the fused step needs twelve different cubes (six before, six after)");
     }
@@ -1281,7 +1240,7 @@ extern "C" int fdtdx_yee2d_steps(int device, float *ex, float *ey, float *hz, ui
 extern "C" int fdtdx_halo_region(fdtdx_ctx *ctx, const char *name, int side, int what, float **ptr, size_t *count)
 {
     float *d;
-    int rc = find_cube(ctx, name, &d);
+    int rc = fdtdx_find_cube(ctx, name, &d);
     if (rc) return rc;
     if (!ptr || !count || (side != 0 && side != 1) || (what != 0 && what != 1)) return fail(FDTDX_ERR_INVALID, "bad halo_region argument");
     const fdtdx_geometry &g = ctx->g;
@@ -1315,6 +1274,8 @@ extern "C" int fdtdx_set_option(fdtdx_ctx *ctx, const char *key, int64_t value)
         ctx->opt_tb_variant = value;
     else if (!strcmp(key, "tb_zchunks"))
         ctx->opt_tb_zchunks = value;
+    else if (!strcmp(key, "reserve_cus"))
+        ctx->opt_reserve_cus = std::max<int64_t>(0, std::min<int64_t>(value, 255));
     else
         return fail(FDTDX_ERR_INVALID, "unknown option '%s'", key);
     return FDTDX_OK;

@@ -1,0 +1,461 @@
+// fdtdx_comm.hip -- ghost-plane exchange between z neighbours, and the boundary-first time step around it.
+//
+// Native counterpart of the halo machinery of the reference (stencil.h:639-682: commCubeHalo, commCubeHaloBackup,
+// backup/restoreCubeHaloBackup) and of the per-step choreography of its drivers (fdtd1.cu:70-78):
+//
+//   reference, per step                               here, per step
+//   -----------------------------------------------   --------------------------------------------------------------
+//   backupCubeHaloBackup      D2D copies 3M planes    --  (ghost planes live inside the cube)
+//   propagateHalo{Top,Buttom}Backup   M planes each   boundary sweeps on the caller's stream, event `ready` behind them
+//   sync; propagate (async)                           exchange on its own stream once `ready` has fired:
+//   commCubeHaloBackup   host-blocking MPI Sendrecv       RCCL  ncclGroupStart; ncclSend/ncclRecv per neighbour; ncclGroupEnd
+//   sync; restoreCubeHaloBackup  D2D copies; sync         local peer copies (copy engines) straight into the neighbour's ghosts
+//                                                     interior sweep on the caller's stream, beside the exchange
+//                                                     the caller's stream waits for event `done`
+//
+// Boundary planes are contiguous in the cube and are received straight into the neighbour's ghost planes of the same
+// cube: no packing, no staging copies.  Two transports:
+//   * RCCL (one process per GPU, the layout the reference runs in: one MPI rank per GPU): send/recv pairs over xGMI.
+//     librccl is opened at run time, so the rest of the library works where it is absent.
+//   * local (all slabs in one process): hipMemcpyPeerAsync / device-to-device copies on the exchange stream.  The
+//     host issues the slabs one after the other, so a step has two phases: begin on every slab, then end on every slab.
+#include "fdtdx_ctx.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+
+namespace {
+
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+int rccl(RcclApi **out)
+{
+    static RcclApi api;
+    static std::mutex m;
+    std::lock_guard<std::mutex> lock(m);
+    if (!api.handle) {
+        // a copy already loaded by the host program (PyTorch ships one under the same soname) is reused by the loader
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        void *h = nullptr;
+        for (const char *n : names)
+            if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) return fail(FDTDX_ERR_UNSUPPORTED, "RCCL not found (librccl.so.1): %s", dlerror());
+#define SYM(field, name)                                                                                  \
+    if (!(api.field = (decltype(api.field))dlsym(h, name))) {                                             \
+        dlclose(h);                                                                                       \
+        return fail(FDTDX_ERR_UNSUPPORTED, "RCCL lacks %s", name);                                        \
+    }
+        SYM(GetUniqueId, "ncclGetUniqueId")
+        SYM(CommInitRank, "ncclCommInitRank")
+        SYM(CommDestroy, "ncclCommDestroy")
+        SYM(GroupStart, "ncclGroupStart")
+        SYM(GroupEnd, "ncclGroupEnd")
+        SYM(Send, "ncclSend")
+        SYM(Recv, "ncclRecv")
+        SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+        api.handle = h;
+    }
+    *out = &api;
+    return FDTDX_OK;
+}
+
+#define NCCL_TRY(api, expr)                                                                              \
+    do {                                                                                                 \
+        ncclResult_t r_ = (expr);                                                                        \
+        if (r_ != ncclSuccess) return fail(FDTDX_ERR_HIP, "%s: %s", #expr, (api)->GetErrorString(r_));   \
+    } while (0)
+
+}  // namespace
+
+enum { COMM_LOCAL = 0, COMM_RCCL = 1 };
+
+struct fdtdx_comm {
+    int mode = COMM_LOCAL;
+    hipStream_t xs = nullptr;       // the exchange stream
+    hipEvent_t ready = nullptr;     // recorded on the caller's stream: the boundary planes of this step are written
+    hipEvent_t done = nullptr;      // recorded on xs: this context's part of the exchange has finished
+    hipEvent_t guard[2] = {nullptr, nullptr};  // local: recorded on THIS context's stream for the neighbour on that side
+    bool marked = false;            // `ready` was recorded explicitly (fdtdx_comm_boundary_done) for the next exchange
+    uint64_t epoch = 0;             // exchanges started
+    uint64_t waited = 0;            // exchanges waited for
+    hipStream_t last_stream = nullptr;
+    // RCCL
+    ncclComm_t comm = nullptr;
+    int peer[2] = {-1, -1};         // communicator ranks of the neighbours below / above
+    // local
+    fdtdx_ctx *nb[2] = {nullptr, nullptr};
+};
+
+// Streams share a few hardware queues, and a wait blocks everything queued behind it in its hardware queue.  The runtime
+// hands a stream's commands to the hardware in batches of its own timing, so a wait can reach a hardware queue before the
+// commands (of another stream on the same queue) that will produce the event it waits for, and then nothing behind it
+// ever runs.  Every event another stream is going to wait on is therefore pushed to the hardware at once, in the order
+// the host produced it: a query of the stream submits what the stream holds.
+static inline void submit_now(hipStream_t s)
+{
+    if (hipStreamQuery(s) != hipSuccess) (void)hipGetLastError();  // "not ready" is the expected answer
+}
+
+static int comm_streams(fdtdx_ctx *ctx, fdtdx_comm *c)
+{
+    USE_DEVICE(ctx);
+    // An ordinary stream.  (A high-priority one, meant to get the exchange's few workgroups ahead of an interior sweep
+    // that fills every CU, left the device waiting for ever once a process had created a handful of streams: the second
+    // two-slab run with a stream per slab never finished.  Room for the exchange is made with the "reserve_cus" option.)
+    HIP_TRY(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+    for (int s = 0; s < 2; s++) HIP_TRY(hipEventCreateWithFlags(&c->guard[s], hipEventDisableTiming));
+    return FDTDX_OK;
+}
+
+void fdtdx_comm_release(fdtdx_ctx *ctx)
+{
+    fdtdx_comm *c = ctx->comm;
+    if (!c) return;
+    (void)hipSetDevice(ctx->device);
+    if (c->xs) (void)hipStreamSynchronize(c->xs);
+    if (c->comm) {
+        RcclApi *api = nullptr;
+        if (rccl(&api) == FDTDX_OK) (void)api->CommDestroy(c->comm);
+    }
+    if (c->ready) (void)hipEventDestroy(c->ready);
+    if (c->done) (void)hipEventDestroy(c->done);
+    for (int s = 0; s < 2; s++)
+        if (c->guard[s]) (void)hipEventDestroy(c->guard[s]);
+    if (c->xs) (void)hipStreamDestroy(c->xs);
+    // a neighbour in this process must not keep pointing here
+    for (int s = 0; s < 2; s++)
+        if (c->nb[s] && c->nb[s]->comm && c->nb[s]->comm->nb[1 - s] == ctx) c->nb[s]->comm->nb[1 - s] = nullptr;
+    delete c;
+    ctx->comm = nullptr;
+}
+
+extern "C" int fdtdx_comm_destroy(fdtdx_ctx *ctx)
+{
+    if (!ctx) return fail(FDTDX_ERR_INVALID, "null context");
+    fdtdx_comm_release(ctx);
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_comm_unique_id(fdtdx_comm_id *id)
+{
+    if (!id) return fail(FDTDX_ERR_INVALID, "null argument");
+    static_assert(sizeof(fdtdx_comm_id) == sizeof(ncclUniqueId), "fdtdx_comm_id carries an ncclUniqueId");
+    RcclApi *api;
+    int rc = rccl(&api);
+    if (rc) return rc;
+    ncclUniqueId u;
+    NCCL_TRY(api, api->GetUniqueId(&u));
+    memcpy(id->bytes, &u, sizeof(u));
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_comm_init_ranks(fdtdx_ctx *ctx, const fdtdx_comm_id *id, int comm_rank, int comm_size, int peer_lo, int peer_hi)
+{
+    if (!ctx || !id) return fail(FDTDX_ERR_INVALID, "null argument");
+    if (ctx->comm) return fail(FDTDX_ERR_EXISTS, "the context already has a communicator");
+    if (comm_rank < 0 || comm_rank >= comm_size) return fail(FDTDX_ERR_INVALID, "communicator rank %d of %d", comm_rank, comm_size);
+    const fdtdx_geometry &g = ctx->g;
+    if ((g.ghost_lo && (peer_lo < 0 || peer_lo >= comm_size)) || (g.ghost_hi && (peer_hi < 0 || peer_hi >= comm_size)))
+        return fail(FDTDX_ERR_INVALID, "neighbour ranks %d / %d outside the communicator of %d", peer_lo, peer_hi, comm_size);
+    RcclApi *api;
+    int rc = rccl(&api);
+    if (rc) return rc;
+    fdtdx_comm *c = new (std::nothrow) fdtdx_comm;
+    if (!c) return fail(FDTDX_ERR_NOMEM, "out of host memory");
+    c->mode = COMM_RCCL;
+    c->peer[0] = g.ghost_lo ? peer_lo : -1, c->peer[1] = g.ghost_hi ? peer_hi : -1;
+    ctx->comm = c;
+    if ((rc = comm_streams(ctx, c))) {
+        fdtdx_comm_release(ctx);
+        return rc;
+    }
+    ncclUniqueId u;
+    memcpy(&u, id->bytes, sizeof(u));
+    const ncclResult_t r = api->CommInitRank(&c->comm, comm_size, u, comm_rank);
+    if (r != ncclSuccess) {
+        c->comm = nullptr;
+        fdtdx_comm_release(ctx);
+        return fail(FDTDX_ERR_HIP, "ncclCommInitRank: %s", api->GetErrorString(r));
+    }
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_comm_init(fdtdx_ctx *ctx, const fdtdx_comm_id *id)
+{
+    if (!ctx) return fail(FDTDX_ERR_INVALID, "null argument");
+    const int r = (int)ctx->cfg.rank, n = (int)ctx->cfg.nprocs;
+    return fdtdx_comm_init_ranks(ctx, id, r, n, r - 1, r + 1);
+}
+
+extern "C" int fdtdx_comm_init_local(fdtdx_ctx *const *ctxs, int n)
+{
+    if (!ctxs || n < 1) return fail(FDTDX_ERR_INVALID, "null argument");
+    for (int i = 0; i < n; i++) {
+        if (!ctxs[i]) return fail(FDTDX_ERR_INVALID, "null context");
+        if (ctxs[i]->comm) return fail(FDTDX_ERR_EXISTS, "slab %d already has a communicator", i);
+        const fdtdx_config &a = ctxs[i]->cfg, &b = ctxs[0]->cfg;
+        if ((int)a.rank != i || (int)a.nprocs != n || a.Z != b.Z || a.Y != b.Y || a.X != b.X || a.M != b.M || ctxs[i]->g.pitch_x != ctxs[0]->g.pitch_x)
+            return fail(FDTDX_ERR_INVALID, "slab %d: the contexts must be ranks 0..%d of one %d-way split of one grid, in order", i, n - 1, n);
+    }
+    for (int i = 0; i < n; i++) {
+        fdtdx_comm *c = new (std::nothrow) fdtdx_comm;
+        if (!c) return fail(FDTDX_ERR_NOMEM, "out of host memory");
+        c->mode = COMM_LOCAL;
+        ctxs[i]->comm = c;
+        int rc = comm_streams(ctxs[i], c);
+        if (rc) {
+            for (int k = 0; k <= i; k++) fdtdx_comm_release(ctxs[k]);
+            return rc;
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        ctxs[i]->comm->nb[0] = i > 0 ? ctxs[i - 1] : nullptr;
+        ctxs[i]->comm->nb[1] = i < n - 1 ? ctxs[i + 1] : nullptr;
+        for (int s = 0; s < 2; s++) {  // let the copy engines reach the neighbour's memory directly
+            fdtdx_ctx *o = ctxs[i]->comm->nb[s];
+            if (o && o->device != ctxs[i]->device) {
+                (void)hipSetDevice(ctxs[i]->device);
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, ctxs[i]->device, o->device) == hipSuccess && can) {
+                    const hipError_t e = hipDeviceEnablePeerAccess(o->device, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                }
+            }
+        }
+    }
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_comm_boundary_done(fdtdx_ctx *ctx, void *stream)
+{
+    if (!ctx || !ctx->comm) return fail(FDTDX_ERR_INVALID, "the context has no communicator");
+    USE_DEVICE(ctx);
+    HIP_TRY(hipEventRecord(ctx->comm->ready, (hipStream_t)stream));
+    submit_now((hipStream_t)stream);
+    ctx->comm->marked = true;
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_comm_exchange_start(fdtdx_ctx *ctx, const char *name, void *stream)
+{
+    if (!ctx || !name) return fail(FDTDX_ERR_INVALID, "null argument");
+    fdtdx_comm *c = ctx->comm;
+    if (!c) return ctx->cfg.nprocs == 1 ? FDTDX_OK : fail(FDTDX_ERR_INVALID, "no communicator: call fdtdx_comm_init or fdtdx_comm_init_local first");
+    if (c->epoch != c->waited) return fail(FDTDX_ERR_INVALID, "the previous exchange has not been waited for (fdtdx_comm_exchange_wait)");
+    float *snd[2], *rcv[2];
+    size_t cnt[2], cnt2;
+    int rc;
+    for (int s = 0; s < 2; s++) {
+        if ((rc = fdtdx_halo_region(ctx, name, s, 0, &snd[s], &cnt[s])) || (rc = fdtdx_halo_region(ctx, name, s, 1, &rcv[s], &cnt2))) return rc;
+    }
+    USE_DEVICE(ctx);
+    hipStream_t st = (hipStream_t)stream;
+    if (!c->marked) {
+        HIP_TRY(hipEventRecord(c->ready, st));  // everything queued so far, the boundary sweeps included
+        submit_now(st);
+    }
+    c->marked = false;
+    HIP_TRY(hipStreamWaitEvent(c->xs, c->ready, 0));
+    if (c->mode == COMM_RCCL) {
+        RcclApi *api;
+        if ((rc = rccl(&api))) return rc;
+        NCCL_TRY(api, api->GroupStart());
+        for (int s = 0; s < 2; s++)
+            if (cnt[s]) {
+                NCCL_TRY(api, api->Send(snd[s], cnt[s], ncclFloat, c->peer[s], c->comm, c->xs));
+                NCCL_TRY(api, api->Recv(rcv[s], cnt[s], ncclFloat, c->peer[s], c->comm, c->xs));
+            }
+        NCCL_TRY(api, api->GroupEnd());
+    } else {
+        for (int s = 0; s < 2; s++) {
+            fdtdx_ctx *o = c->nb[s];
+            if (!cnt[s]) continue;
+            if (!o || !o->comm) return fail(FDTDX_ERR_INVALID, "the neighbouring slab is gone");
+            // The copy lands in the neighbour's ghost planes of this cube, which the neighbour's sweeps queued so far may
+            // still read (as the input of its previous step): wait for all it has queued.
+            if (o->comm->last_stream || o->comm->epoch) {
+                HIP_TRY(hipSetDevice(o->device));
+                HIP_TRY(hipEventRecord(o->comm->guard[1 - s], o->comm->last_stream));
+                submit_now(o->comm->last_stream);
+                HIP_TRY(hipSetDevice(ctx->device));
+                HIP_TRY(hipStreamWaitEvent(c->xs, o->comm->guard[1 - s], 0));
+            }
+            float *dst;
+            size_t dcnt;
+            if ((rc = fdtdx_halo_region(o, name, 1 - s, 1, &dst, &dcnt))) return rc;
+            if (dcnt != cnt[s]) return fail(FDTDX_ERR_INVALID, "the neighbouring slab has another geometry");
+            USE_DEVICE(ctx);
+            if (o->device == ctx->device)
+                HIP_TRY(hipMemcpyAsync(dst, snd[s], cnt[s] * sizeof(float), hipMemcpyDeviceToDevice, c->xs));
+            else
+                HIP_TRY(hipMemcpyPeerAsync(dst, o->device, snd[s], ctx->device, cnt[s] * sizeof(float), c->xs));
+        }
+    }
+    HIP_TRY(hipEventRecord(c->done, c->xs));
+    submit_now(c->xs);
+    c->last_stream = st;
+    c->epoch++;
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_comm_exchange_wait(fdtdx_ctx *ctx, void *stream)
+{
+    if (!ctx) return fail(FDTDX_ERR_INVALID, "null argument");
+    fdtdx_comm *c = ctx->comm;
+    if (!c) return ctx->cfg.nprocs == 1 ? FDTDX_OK : fail(FDTDX_ERR_INVALID, "no communicator");
+    if (c->waited == c->epoch) return FDTDX_OK;  // nothing in flight
+    USE_DEVICE(ctx);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipStreamWaitEvent(st, c->done, 0));  // RCCL: sends and receives; local: the copies out of this cube
+    if (c->mode == COMM_LOCAL)
+        for (int s = 0; s < 2; s++) {  // the copies INTO this cube are the neighbours' work
+            fdtdx_ctx *o = c->nb[s];
+            if (!o || !o->comm) continue;
+            if (o->comm->epoch != c->epoch)
+                return fail(FDTDX_ERR_INVALID, "slabs in one process exchange in two phases: start the exchange on every slab, then wait on every slab");
+            HIP_TRY(hipStreamWaitEvent(st, o->comm->done, 0));
+        }
+    c->waited = c->epoch;
+    c->last_stream = st;
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_comm_cube_halo(fdtdx_ctx *ctx, const char *name, void *stream)
+{
+    if (ctx && ctx->comm && ctx->comm->mode == COMM_LOCAL && ctx->cfg.nprocs > 1)
+        return fail(FDTDX_ERR_UNSUPPORTED, "slabs in one process exchange in two phases: fdtdx_comm_exchange_start on every slab, then fdtdx_comm_exchange_wait");
+    int rc = fdtdx_comm_exchange_start(ctx, name, stream);
+    return rc ? rc : fdtdx_comm_exchange_wait(ctx, stream);
+}
+
+// ---- the time step of a multi-rank driver (fdtd1.cu:70-78) ------------------------------------------------------
+static void update_range(const fdtdx_ctx *ctx, uint64_t r, uint64_t *lo, uint64_t *hi)
+{
+    const fdtdx_geometry &g = ctx->g;
+    *lo = g.ghost_lo ? g.ghost_lo : r;
+    *hi = g.ghost_hi ? g.local_planes - g.ghost_hi : g.local_planes - r;
+}
+
+// boundary planes first, the exchange behind them, the interior beside the exchange
+template <class Sweep>
+static int split_step(fdtdx_ctx *ctx, const char *out, uint64_t r, void *stream, Sweep &&sweep)
+{
+    const fdtdx_geometry &g = ctx->g;
+    const uint64_t G = ctx->cfg.M;
+    uint64_t lo, hi;
+    update_range(ctx, r, &lo, &hi);
+    uint64_t ilo = lo, ihi = hi;
+    int rc;
+    if (g.ghost_lo) {
+        ilo = std::min(lo + G, hi);
+        if ((rc = sweep(lo, ilo))) return rc;
+    }
+    if (g.ghost_hi) {
+        ihi = std::max(hi - G, ilo);
+        if ((rc = sweep(ihi, hi))) return rc;
+    }
+    if ((rc = fdtdx_comm_exchange_start(ctx, out, stream))) return rc;
+    return sweep(ilo, ihi);
+}
+
+static int program_radius(const fdtdx_program *prog, uint64_t *r)
+{
+    if (!prog) return fail(FDTDX_ERR_INVALID, "null program");
+    *r = prog->kind == FDTDX_STAR ? prog->radius : 1;
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_step_begin(fdtdx_ctx *ctx, const char *out, const char *in, const fdtdx_program *prog, void *stream)
+{
+    if (!ctx) return fail(FDTDX_ERR_INVALID, "null context");
+    uint64_t r;
+    int rc = program_radius(prog, &r);
+    if (rc) return rc;
+    return split_step(ctx, out, r, stream, [&](uint64_t z0, uint64_t z1) { return z1 > z0 ? fdtdx_propagate_planes(ctx, out, in, prog, z0, z1, stream) : FDTDX_OK; });
+}
+
+extern "C" int fdtdx_hop_begin(fdtdx_ctx *ctx, const char *out, const char *in, const char *shell_even, const char *shell_odd,
+                               const fdtdx_program *prog, uint32_t nsteps, void *stream)
+{
+    if (!ctx) return fail(FDTDX_ERR_INVALID, "null context");
+    uint64_t r;
+    int rc = program_radius(prog, &r);
+    if (rc) return rc;
+    return split_step(ctx, out, r, stream, [&](uint64_t z0, uint64_t z1) {
+        return z1 > z0 ? fdtdx_propagate_fused_shells(ctx, out, in, shell_even, shell_odd, prog, nsteps, z0, z1, stream) : FDTDX_OK;
+    });
+}
+
+extern "C" int fdtdx_step_end(fdtdx_ctx *ctx, void *stream) { return fdtdx_comm_exchange_wait(ctx, stream); }
+
+// The drivers' whole loop on n slabs (fdtd1.cu:68-80): n = 1 for a process that owns one slab and talks to the others
+// through its RCCL communicator, n = all slabs for a process that owns them all.  Level t lives in b for even t and in a
+// for odd t; fused launches where the ghost depth allows them; the last steps are single steps, so that a and b finish
+// holding the two newest levels.
+extern "C" int fdtdx_run(fdtdx_ctx *const *ctxs, int n, const char *a, const char *b, const fdtdx_program *prog, uint32_t steps,
+                         void *const *streams)
+{
+    if (!ctxs || n < 1 || !a || !b) return fail(FDTDX_ERR_INVALID, "null argument");
+    uint64_t r;
+    int rc = program_radius(prog, &r);
+    if (rc) return rc;
+    for (int i = 0; i < n; i++)
+        if (!ctxs[i]) return fail(FDTDX_ERR_INVALID, "null context");
+    auto stream_of = [&](int i) { return streams ? streams[i] : nullptr; };
+    // how many steps a launch may fuse: the deepest kernel the library has for the program that the ghost depth supports
+    // towards a neighbour (k steps of radius r reach k*r planes) and that can run between the two cubes alone
+    int kt = 0;
+    {
+        int64_t want = ctxs[0]->opt_temporal;
+        const uint64_t G = ctxs[0]->cfg.M;
+        const bool multi = ctxs[0]->cfg.nprocs > 1;
+        const bool r1 = (prog->kind == FDTDX_STAR && prog->radius == 1) || prog->kind == FDTDX_JACOBI7;
+        if (steps >= 4 && want != 0) {
+            if (r1 && want != 2 && (!multi || G >= 3 * r)) kt = 3;                              // straight between the two cubes
+            else if (prog->kind == FDTDX_SPC13 && want != 3 && (!multi || G >= 2 * r)) kt = 2;  // in place via the named shell sources
+        }
+    }
+    auto each = [&](auto &&f) {
+        for (int i = 0; i < n; i++)
+            if (int e = f(i)) return e;
+        return 0;
+    };
+    uint32_t done = 0;
+    if (kt == 3) {
+        for (uint32_t k = 0; k < (steps - 1) / 3; k++) {
+            const char *out = (done % 2 == 0) ? a : b, *in = (done % 2 == 0) ? b : a;
+            if ((rc = each([&](int i) { return fdtdx_hop_begin(ctxs[i], out, in, in, out, prog, 3, stream_of(i)); }))) return rc;
+            if ((rc = each([&](int i) { return fdtdx_step_end(ctxs[i], stream_of(i)); }))) return rc;
+            done += 3;
+        }
+    } else if (kt == 2) {
+        for (uint32_t k = 0; k < 2 * ((steps - 1) / 4); k++) {
+            const char *out = (k % 2 == 0) ? a : b, *in = (k % 2 == 0) ? b : a;
+            if ((rc = each([&](int i) { return fdtdx_hop_begin(ctxs[i], out, in, b, a, prog, 2, stream_of(i)); }))) return rc;
+            if ((rc = each([&](int i) { return fdtdx_step_end(ctxs[i], stream_of(i)); }))) return rc;
+            done += 2;
+        }
+    }
+    for (uint32_t t = done; t < steps; t++) {
+        const char *out = (t % 2 == 0) ? a : b, *in = (t % 2 == 0) ? b : a;
+        if ((rc = each([&](int i) { return fdtdx_step_begin(ctxs[i], out, in, prog, stream_of(i)); }))) return rc;
+        if ((rc = each([&](int i) { return fdtdx_step_end(ctxs[i], stream_of(i)); }))) return rc;
+    }
+    return FDTDX_OK;
+}

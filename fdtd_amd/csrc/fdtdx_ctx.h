@@ -1,0 +1,64 @@
+// fdtdx_ctx.h -- what the translation units behind the C ABI (fdtdx_abi.hip, fdtdx_comm.hip) share: the context
+// object, error reporting, device selection.  Private to the library.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+
+#include "../../include/fdtdx.h"
+
+// ---- error reporting: every entry point returns a code and leaves a message for fdtdx_last_error() ----
+int fdtdx_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+#define fail fdtdx_fail
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(FDTDX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct Cube {
+    float *ptr = nullptr;
+    bool owned = false;
+};
+
+struct fdtdx_comm;  // the exchange state of a context (fdtdx_comm.hip)
+
+struct fdtdx_ctx {
+    fdtdx_config cfg;
+    fdtdx_geometry g;
+    int device = 0;
+    std::map<std::string, Cube> pool;  // memoryPool of stencil.h:361
+    struct AddrList {
+        uint64_t *ptr = nullptr;
+        size_t capacity = 0, count = 0;
+    };
+    std::map<std::string, AddrList> addr;  // address lists (stencil.h:363: addrLen)
+    int64_t opt_zchunks = 0;           // 0 = auto
+    int64_t opt_variant = -1;          // -1 = auto
+    int64_t opt_temporal = 1;          // fuse two steps per launch where a fused kernel exists
+    int64_t opt_tb_variant = -1;       // shape of the fused kernel, -1 = auto
+    int64_t opt_tb_zchunks = 0;
+    int64_t opt_reserve_cus = 0;       // CUs a sweep launch leaves without a workgroup (room for the exchange's kernels)
+    float *tb_scratch = nullptr;       // third cube of the fused time loop (owned)
+    float *saved_sum = nullptr;        // fdtdx_composite_step: sum values at the injection addresses
+    size_t saved_cap = 0;
+    float *static_scratch = nullptr;   // device address of the file-scope `scratch` array on ctx->device
+    uint64_t launches = 0;             // sweep launches issued so far (bench bookkeeping)
+    char last_launch[256] = "";
+    char last_fused[256] = "";         // last fused (two-step) launch, "" if none since creation
+    fdtdx_comm *comm = nullptr;        // set by fdtdx_comm_init / fdtdx_comm_init_local
+};
+
+// Every entry point that touches the GPU first makes the context's device current, so that several
+// contexts in one process (one per GPU, or a thread whose current device is another one) reach the right
+// card.  (The reference never selects a device: one rank sees one GPU, run.sh:20.)
+#define USE_DEVICE(ctx)                                              \
+    do {                                                             \
+        if (!(ctx)) return fail(FDTDX_ERR_INVALID, "null context");  \
+        HIP_TRY(hipSetDevice((ctx)->device));                        \
+    } while (0)
+
+int fdtdx_find_cube(fdtdx_ctx *ctx, const char *name, float **p);
+void fdtdx_comm_release(fdtdx_ctx *ctx);  // called by fdtdx_destroy

@@ -101,6 +101,19 @@ SYMBOLS = {
     "fdtdx_yee2d_steps": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_float, ctypes.c_float, ctypes.c_uint32, _vp]),
     "fdtdx_halo_region": (ctypes.c_int, [_vp, _c, ctypes.c_int, ctypes.c_int, _P(_vp), _P(ctypes.c_size_t)]),
+    "fdtdx_comm_unique_id": (ctypes.c_int, [_vp]),
+    "fdtdx_comm_init": (ctypes.c_int, [_vp, _vp]),
+    "fdtdx_comm_init_ranks": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "fdtdx_comm_init_local": (ctypes.c_int, [_P(_vp), ctypes.c_int]),
+    "fdtdx_comm_destroy": (ctypes.c_int, [_vp]),
+    "fdtdx_comm_boundary_done": (ctypes.c_int, [_vp, _vp]),
+    "fdtdx_comm_exchange_start": (ctypes.c_int, [_vp, _c, _vp]),
+    "fdtdx_comm_exchange_wait": (ctypes.c_int, [_vp, _vp]),
+    "fdtdx_comm_cube_halo": (ctypes.c_int, [_vp, _c, _vp]),
+    "fdtdx_step_begin": (ctypes.c_int, [_vp, _c, _c, _P(Program), _vp]),
+    "fdtdx_hop_begin": (ctypes.c_int, [_vp, _c, _c, _c, _c, _P(Program), ctypes.c_uint32, _vp]),
+    "fdtdx_step_end": (ctypes.c_int, [_vp, _vp]),
+    "fdtdx_run": (ctypes.c_int, [_P(_vp), ctypes.c_int, _c, _c, _P(Program), ctypes.c_uint32, _P(_vp)]),
     "fdtdx_set_option": (ctypes.c_int, [_vp, _c, ctypes.c_int64]),
     "fdtdx_last_launch_info": (ctypes.c_int, [_vp, _c, ctypes.c_size_t]),
 }

@@ -228,6 +228,59 @@ class Stencil:
         _lib.check(self._L.fdtdx_halo_region(self._h, name.encode(), side, what, ctypes.byref(p), ctypes.byref(n)))
         return p.value, n.value
 
+    # -- exchange with the z neighbours and the boundary-first step: stencil.h:639-682, fdtd1.cu:70-78 ------------
+    @staticmethod
+    def commUniqueId():
+        """128 bytes naming a new RCCL communicator: made on rank 0, handed to every rank by the launcher."""
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.load().fdtdx_comm_unique_id(buf))
+        return buf.raw
+
+    def commInit(self, comm_id, comm_rank=None, comm_size=None, peer_lo=None, peer_hi=None):
+        """Join the RCCL communicator `comm_id` (one process per slab); ranks default to the slab's own."""
+        buf = ctypes.create_string_buffer(bytes(comm_id), 128)
+        if comm_rank is None:
+            _lib.check(self._L.fdtdx_comm_init(self._h, buf))
+        else:
+            _lib.check(self._L.fdtdx_comm_init_ranks(self._h, buf, comm_rank, comm_size, peer_lo, peer_hi))
+
+    @staticmethod
+    def commInitLocal(stencils):
+        """Link the slabs of ranks 0..n-1, all owned by this process (copy-engine transfers instead of RCCL)."""
+        arr = (ctypes.c_void_p * len(stencils))(*[s._h for s in stencils])
+        _lib.check(_lib.load().fdtdx_comm_init_local(arr, len(stencils)))
+
+    def commBoundaryDone(self, stream=None):
+        _lib.check(self._L.fdtdx_comm_boundary_done(self._h, ctypes.c_void_p(stream or 0)))
+
+    def commExchangeStart(self, name, stream=None):
+        _lib.check(self._L.fdtdx_comm_exchange_start(self._h, name.encode(), ctypes.c_void_p(stream or 0)))
+
+    def commExchangeWait(self, stream=None):
+        _lib.check(self._L.fdtdx_comm_exchange_wait(self._h, ctypes.c_void_p(stream or 0)))
+
+    def commCubeHalo(self, name, stream=None):
+        """commCubeHalo (stencil.h:639-647): stream-ordered, not host-blocking."""
+        _lib.check(self._L.fdtdx_comm_cube_halo(self._h, name.encode(), ctypes.c_void_p(stream or 0)))
+
+    def stepBegin(self, output, input, program, stream=None):
+        _lib.check(self._L.fdtdx_step_begin(self._h, output.encode(), input.encode(), ctypes.byref(program), ctypes.c_void_p(stream or 0)))
+
+    def hopBegin(self, output, input, shell_even, shell_odd, program, nsteps, stream=None):
+        _lib.check(self._L.fdtdx_hop_begin(self._h, output.encode(), input.encode(), shell_even.encode(), shell_odd.encode(),
+                                           ctypes.byref(program), nsteps, ctypes.c_void_p(stream or 0)))
+
+    def stepEnd(self, stream=None):
+        _lib.check(self._L.fdtdx_step_end(self._h, ctypes.c_void_p(stream or 0)))
+
+    @staticmethod
+    def run(stencils, a, b, program, steps, streams=None):
+        """The drivers' whole loop (fdtd1.cu:68-80) on the slabs this process owns (one with RCCL, all in local mode)."""
+        n = len(stencils)
+        arr = (ctypes.c_void_p * n)(*[s._h for s in stencils])
+        st = (ctypes.c_void_p * n)(*[ctypes.c_void_p(x or 0) for x in streams]) if streams else None
+        _lib.check(_lib.load().fdtdx_run(arr, n, a.encode(), b.encode(), ctypes.byref(program), steps, st))
+
     # -- tuning ------------------------------------------------------------------------------
     def setOption(self, key, value):
         _lib.check(self._L.fdtdx_set_option(self._h, key.encode(), int(value)))

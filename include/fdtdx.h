@@ -182,8 +182,51 @@ int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const fdtdx_progra
 /* Ghost-plane exchange regions (commCubeHalo, stencil.h:639-647): pointer/count of the planes to
  * SEND to (what = 0) or RECEIVE from (what = 1) the neighbour on `side` (0 = rank-1, 1 = rank+1).
  * count = M*plane floats, or 0 when there is no neighbour on that side.  Planes are contiguous,
- * so the region is handed to RCCL send/recv (or hipMemcpyPeer) without packing. */
+ * so the region is handed to RCCL send/recv (or hipMemcpyPeer) without packing; the exchange
+ * functions below do exactly that. */
 int fdtdx_halo_region(fdtdx_ctx *ctx, const char *name, int side, int what, float **ptr, size_t *count);
+
+/* ---- ghost-plane exchange with the z neighbours and the boundary-first time step ---------------------------------
+ * commCubeHalo / commCubeHaloBackup with backup/restoreCubeHaloBackup (stencil.h:639-682) and the per-step sequence of
+ * the drivers (fdtd1.cu:70-78).  The first and last M owned planes of a cube go to the neighbours' ghost planes of the
+ * same cube (fdtdx_halo_region names them); no side buffers, no staging copies.  The exchange runs on a stream of its
+ * own, ordered behind the boundary sweeps by an event, while the interior sweep runs on the caller's stream.
+ *
+ * Two transports.  RCCL: one process per slab (the reference's layout, one MPI rank per GPU); rank 0 makes an id with
+ * fdtdx_comm_unique_id, the launcher hands its 128 bytes to every rank (MPI_Bcast where the reference calls MPI_Init,
+ * stencil.h:389; torch.distributed or a file elsewhere), every rank calls fdtdx_comm_init.  Local: one process owns every
+ * slab (fdtdx_comm_init_local on the contexts of ranks 0..n-1, each on its own device or several on one); copies go
+ * through the copy engines.  A single host thread issues the slabs one after the other, so in local mode every exchange
+ * (and every step below) is two phases: start / begin on EVERY slab, then wait / end on EVERY slab. */
+typedef struct { char bytes[128]; } fdtdx_comm_id;
+int fdtdx_comm_unique_id(fdtdx_comm_id *id);
+int fdtdx_comm_init(fdtdx_ctx *ctx, const fdtdx_comm_id *id);
+/* The same with the communicator laid out by the caller: this context is rank comm_rank of comm_size, its z neighbours
+ * are ranks peer_lo / peer_hi (ignored where the slab has no neighbour). */
+int fdtdx_comm_init_ranks(fdtdx_ctx *ctx, const fdtdx_comm_id *id, int comm_rank, int comm_size, int peer_lo, int peer_hi);
+int fdtdx_comm_init_local(fdtdx_ctx *const *ctxs, int n);
+int fdtdx_comm_destroy(fdtdx_ctx *ctx); /* fdtdx_destroy does it too */
+/* Start the exchange of cube `name` behind everything queued on `stream` so far (or behind the point last marked with
+ * fdtdx_comm_boundary_done, for drivers that queue the interior sweep before they call the exchange, as fdtd1.cu:70-75
+ * does) / make work queued on `stream` after the call see the received ghost planes.  cube_halo = start + wait. */
+int fdtdx_comm_boundary_done(fdtdx_ctx *ctx, void *stream);
+int fdtdx_comm_exchange_start(fdtdx_ctx *ctx, const char *name, void *stream);
+int fdtdx_comm_exchange_wait(fdtdx_ctx *ctx, void *stream);
+int fdtdx_comm_cube_halo(fdtdx_ctx *ctx, const char *name, void *stream);
+/* One time step of a multi-rank driver, fdtd1.cu:70-78: sweeps of the M planes next to each neighbour
+ * (propagateHalo{Top,Buttom}Backup), the exchange of `out` started behind them, the interior sweep beside it (begin);
+ * the caller's stream waits for the exchange (end).  hop: the same around one fused launch of nsteps steps
+ * (fdtdx_propagate_fused_shells; the context's ghost depth M must be nsteps x radius). */
+int fdtdx_step_begin(fdtdx_ctx *ctx, const char *out, const char *in, const fdtdx_program *prog, void *stream);
+int fdtdx_hop_begin(fdtdx_ctx *ctx, const char *out, const char *in, const char *shell_even, const char *shell_odd,
+                    const fdtdx_program *prog, uint32_t nsteps, void *stream);
+int fdtdx_step_end(fdtdx_ctx *ctx, void *stream);
+/* The drivers' whole loop (fdtd1.cu:68-80) on n slabs: n = 1 for a process that owns one slab and reaches the others
+ * through RCCL, n = all slabs of a process that owns them all (streams[i]: the stream of slab i, NULL = default streams).
+ * Fuses three steps per launch for radius-1 programs and two for the 13-point program where the ghost depth allows
+ * (M >= 3, M >= 2); on return a / b hold what the reference's cubes hold after `steps` steps. */
+int fdtdx_run(fdtdx_ctx *const *ctxs, int n, const char *a, const char *b, const fdtdx_program *prog, uint32_t steps,
+              void *const *streams);
 
 /* ---- the composite pipeline of main.cu (the only caller of inject / filt / address lists) ------------ */
 
@@ -276,7 +319,8 @@ int fdtdx_yee2d_steps(int device, float *ex, float *ey, float *hz, uint64_t nx, 
 /* Kernel-selection knobs, for tuning and tests: "zchunks" (z-chunks per sweep launch, 0 = auto),
  * "variant" (tile-shape index, -1 = auto), "temporal" (time steps fdtdx_sweep fuses per launch where
  * a fused kernel exists: 1 = as many as there is a kernel for, 2, 3, or 0 = one launch per step),
- * "tb_variant" / "tb_zchunks" (shape and z-chunks of the fused kernel). */
+ * "tb_variant" / "tb_zchunks" (shape and z-chunks of the fused kernel), "reserve_cus" (CUs a sweep launch leaves
+ * without a workgroup when it sizes its grid: room for the exchange's kernels beside an interior sweep). */
 int fdtdx_set_option(fdtdx_ctx *ctx, const char *key, int64_t value);
 /* Describes the kernels the last sweeps launched (tile shape, grid, LDS; the last fused launch if
  * any; launches issued so far), for logs and bench. */
