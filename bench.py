@@ -150,10 +150,15 @@ def main():
                     help="time steps fused per launch where a fused kernel exists: 1 = deepest (default), 2, 3, 0 = none")
     ap.add_argument("--spinup-ms", type=float, default=100.0,
                     help="untimed device spin-up before the warm-up steps (fields restored afterwards); 0 = none")
+    ap.add_argument("--reserve-cus", type=int, default=0,
+                    help="N > 1, native exchange: CUs the sweep launches leave free for the exchange's kernels")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-standing-start", dest="standing_start", action="store_false",
                     help="skip the extra 1000-step run from a standing start (one rank, sweep variants)")
     ap.add_argument("--all-variants", action="store_true", help="also time every other variant (N=1 only)")
+    ap.add_argument("--exchange", default="native", choices=["native", "torch"],
+                    help="N > 1: who moves the ghost planes -- native: the library's own RCCL send/recv on its exchange stream "
+                         "(fdtdx_run); torch: torch.distributed P2P ops issued from Python (fdtd_amd.slab.SlabRunner)")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="run the N>1 loop with every rank on cuda:0 and host-staged gloo exchange (1-GPU box rehearsal; "
                          "the line is marked rehearsal and is not a measurement)")
@@ -164,7 +169,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from fdtd_amd import make_program
+    from fdtd_amd import Stencil, make_program
     from fdtd_amd.slab import HipSlabBackend, SlabRunner
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -319,9 +324,15 @@ def main():
         n = a.n
         # ghost depth: the program radius, or, on several slabs, what the fused kernels need to run with one
         # exchange per launch: 3 for radius-1 programs (three steps), 4 for radius 2 (two steps)
+        native = world > 1 and a.exchange == "native" and not a.rehearse_shared_gpu
         ghost = radius
-        if world > 1 and kind in ("star", "jacobi7") and radius <= 2 and a.temporal != 0:
-            ghost = 3 if radius == 1 else 4
+        if world > 1 and a.temporal != 0:
+            if kind in ("star", "jacobi7") and radius == 1:
+                ghost = 3
+            elif kind == "star" and radius == 2 and not native:
+                ghost = 4  # the radius-2 fused kernel needs a third cube on slabs: the Python loop allocates one, fdtdx_run steps singly
+            elif kind == "spc13":
+                ghost = 2
         Zg, Yg, Xg = ([int(v) for v in a.grid.split(",")] if a.grid else [n * world, n, n])
         be = HipSlabBackend(Zg, Yg, Xg, ghost, rank, world, local_rank)
         be.alloc("p0")
@@ -335,12 +346,21 @@ def main():
         be.st.setOption("temporal", a.temporal)
         run = SlabRunner(be, ghost, prog, rank, world, exchange="host" if a.rehearse_shared_gpu else "device")
         cs = torch.cuda.current_stream().cuda_stream
+        if native:
+            # the library's own communicator: rank 0 makes the id, torch.distributed carries its 128 bytes to the others
+            box = [Stencil.commUniqueId() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            be.st.commInit(box[0])
+            if a.reserve_cus:
+                be.st.setOption("reserve_cus", a.reserve_cus)
 
         def loop(k):
             if world == 1:
                 # one rank: the whole time loop runs inside the library (fdtdx_sweep, the drivers'
                 # loop of fdtd1.cu:68-80), which fuses two steps per launch where it can
                 be.st.sweep("p0", "p1", prog, k, cs)
+            elif native:
+                Stencil.run([be.st], "p0", "p1", prog, k, [cs])
             else:
                 run.run("p0", "p1", k, fuse=a.temporal != 0)
 
@@ -504,6 +524,13 @@ def main():
     if a.rehearse_shared_gpu:
         line["rehearsal"] = "ranks share one GPU, host-staged gloo exchange: NOT a measurement"
     if world > 1:
+        who = [None] * world
+        dist.all_gather_object(who, {"rank": rank, "device": local_rank, "name": torch.cuda.get_device_name(local_rank)})
+        line["ranks"] = who
+        line["config"]["exchange"] = ("host-staged gloo (rehearsal)" if a.rehearse_shared_gpu else
+                                      "RCCL send/recv issued by the library on its exchange stream (fdtdx_run)" if a.exchange == "native"
+                                      else "torch.distributed batch_isend_irecv on the nccl (= RCCL) backend")
+        line["config"]["world_size"] = dist.get_world_size()
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -93,6 +93,7 @@ struct fdtdx_comm {
     uint64_t epoch = 0;             // exchanges started
     uint64_t waited = 0;            // exchanges waited for
     hipStream_t last_stream = nullptr;
+    float *token = nullptr;         // two floats of device memory passed along the chain by fdtdx_comm_barrier
     // RCCL
     ncclComm_t comm = nullptr;
     int peer[2] = {-1, -1};         // communicator ranks of the neighbours below / above
@@ -120,6 +121,7 @@ static int comm_streams(fdtdx_ctx *ctx, fdtdx_comm *c)
     HIP_TRY(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
     for (int s = 0; s < 2; s++) HIP_TRY(hipEventCreateWithFlags(&c->guard[s], hipEventDisableTiming));
+    HIP_TRY(hipMalloc((void **)&c->token, 256));
     return FDTDX_OK;
 }
 
@@ -138,6 +140,7 @@ void fdtdx_comm_release(fdtdx_ctx *ctx)
     for (int s = 0; s < 2; s++)
         if (c->guard[s]) (void)hipEventDestroy(c->guard[s]);
     if (c->xs) (void)hipStreamDestroy(c->xs);
+    if (c->token) (void)hipFree(c->token);
     // a neighbour in this process must not keep pointing here
     for (int s = 0; s < 2; s++)
         if (c->nb[s] && c->nb[s]->comm && c->nb[s]->comm->nb[1 - s] == ctx) c->nb[s]->comm->nb[1 - s] = nullptr;
@@ -342,6 +345,38 @@ extern "C" int fdtdx_comm_cube_halo(fdtdx_ctx *ctx, const char *name, void *stre
         return fail(FDTDX_ERR_UNSUPPORTED, "slabs in one process exchange in two phases: fdtdx_comm_exchange_start on every slab, then fdtdx_comm_exchange_wait");
     int rc = fdtdx_comm_exchange_start(ctx, name, stream);
     return rc ? rc : fdtdx_comm_exchange_wait(ctx, stream);
+}
+
+// Stencil::barrier (stencil.h:435-438, MPI Barrier): every slab's queued work has finished and every rank has arrived.
+// RCCL: a token travels up the chain of slabs and back down (each rank receives from below, sends up, receives from
+// above, sends down), then the exchange stream is drained; local: the devices of this slab and its neighbours are drained.
+extern "C" int fdtdx_comm_barrier(fdtdx_ctx *ctx)
+{
+    if (!ctx) return fail(FDTDX_ERR_INVALID, "null context");
+    USE_DEVICE(ctx);
+    HIP_TRY(hipDeviceSynchronize());
+    fdtdx_comm *c = ctx->comm;
+    if (!c) return ctx->cfg.nprocs == 1 ? FDTDX_OK : fail(FDTDX_ERR_INVALID, "no communicator");
+    if (c->mode == COMM_LOCAL) {
+        for (int s = 0; s < 2; s++)
+            for (fdtdx_ctx *o = c->nb[s]; o; o = o->comm ? o->comm->nb[s] : nullptr) {
+                HIP_TRY(hipSetDevice(o->device));
+                HIP_TRY(hipDeviceSynchronize());
+            }
+        HIP_TRY(hipSetDevice(ctx->device));
+        return FDTDX_OK;
+    }
+    RcclApi *api;
+    int rc = rccl(&api);
+    if (rc) return rc;
+    if (c->peer[0] >= 0) NCCL_TRY(api, api->Recv(c->token, 1, ncclFloat, c->peer[0], c->comm, c->xs));
+    if (c->peer[1] >= 0) {
+        NCCL_TRY(api, api->Send(c->token, 1, ncclFloat, c->peer[1], c->comm, c->xs));
+        NCCL_TRY(api, api->Recv(c->token + 1, 1, ncclFloat, c->peer[1], c->comm, c->xs));
+    }
+    if (c->peer[0] >= 0) NCCL_TRY(api, api->Send(c->token + 1, 1, ncclFloat, c->peer[0], c->comm, c->xs));
+    HIP_TRY(hipStreamSynchronize(c->xs));
+    return FDTDX_OK;
 }
 
 // ---- the time step of a multi-rank driver (fdtd1.cu:70-78) ------------------------------------------------------

@@ -106,6 +106,7 @@ SYMBOLS = {
     "fdtdx_comm_init_ranks": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "fdtdx_comm_init_local": (ctypes.c_int, [_P(_vp), ctypes.c_int]),
     "fdtdx_comm_destroy": (ctypes.c_int, [_vp]),
+    "fdtdx_comm_barrier": (ctypes.c_int, [_vp]),
     "fdtdx_comm_boundary_done": (ctypes.c_int, [_vp, _vp]),
     "fdtdx_comm_exchange_start": (ctypes.c_int, [_vp, _c, _vp]),
     "fdtdx_comm_exchange_wait": (ctypes.c_int, [_vp, _vp]),

@@ -250,6 +250,10 @@ class Stencil:
         arr = (ctypes.c_void_p * len(stencils))(*[s._h for s in stencils])
         _lib.check(_lib.load().fdtdx_comm_init_local(arr, len(stencils)))
 
+    def barrier(self):
+        """stencil.h:435-438."""
+        _lib.check(self._L.fdtdx_comm_barrier(self._h))
+
     def commBoundaryDone(self, stream=None):
         _lib.check(self._L.fdtdx_comm_boundary_done(self._h, ctypes.c_void_p(stream or 0)))
 

@@ -206,6 +206,8 @@ int fdtdx_comm_init(fdtdx_ctx *ctx, const fdtdx_comm_id *id);
 int fdtdx_comm_init_ranks(fdtdx_ctx *ctx, const fdtdx_comm_id *id, int comm_rank, int comm_size, int peer_lo, int peer_hi);
 int fdtdx_comm_init_local(fdtdx_ctx *const *ctxs, int n);
 int fdtdx_comm_destroy(fdtdx_ctx *ctx); /* fdtdx_destroy does it too */
+/* Stencil::barrier (stencil.h:435-438): this slab's queued work has finished and every slab of the chain has arrived. */
+int fdtdx_comm_barrier(fdtdx_ctx *ctx);
 /* Start the exchange of cube `name` behind everything queued on `stream` so far (or behind the point last marked with
  * fdtdx_comm_boundary_done, for drivers that queue the interior sweep before they call the exchange, as fdtd1.cu:70-75
  * does) / make work queued on `stream` after the call see the received ghost planes.  cube_halo = start + wait. */

@@ -7,6 +7,7 @@
 // `fdtdx_program` (a C ABI cannot carry a lambda), and rank/nprocs come from the constructor
 // instead of MPI::COMM_WORLD (the launcher owns the communicator here).
 #pragma once
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -64,6 +65,25 @@ class Stencil {
     static_assert(std::is_same<DataType, float>::value, "the sweep kernels are fp32 (every shipped driver uses float)");
     fdtdx_ctx *ctx_ = nullptr;
     fdtdx_geometry g_{};
+    std::string boundary_of_;                // the cube whose boundary planes have been swept ahead of the interior
+    bool done_lo_ = false, done_hi_ = false;
+
+    void halo_sweep(const std::string &output, const std::string &input, bool, const fdtdx_program &prog, void *stream, int side)
+    {
+        if (boundary_of_ != output) boundary_of_ = output, done_lo_ = done_hi_ = false;
+        const uint64_t r = prog.kind == FDTDX_STAR ? prog.radius : 1;
+        const uint64_t lo = g_.ghost_lo ? g_.ghost_lo : r, hi = g_.ghost_hi ? g_.local_planes - g_.ghost_hi : g_.local_planes - r;
+        if (side == 0 && g_.ghost_lo) {
+            FDTDX_ASSERT(fdtdx_propagate_planes(ctx_, output.c_str(), input.c_str(), &prog, lo, std::min<uint64_t>(lo + M, hi), stream));
+            done_lo_ = true;
+        }
+        if (side == 1 && g_.ghost_hi) {
+            const uint64_t first = std::max<uint64_t>(hi - M, done_lo_ ? std::min<uint64_t>(lo + M, hi) : lo);
+            FDTDX_ASSERT(fdtdx_propagate_planes(ctx_, output.c_str(), input.c_str(), &prog, first, hi, stream));
+            done_hi_ = true;
+        }
+        if (g_.ghost_lo || g_.ghost_hi) FDTDX_ASSERT(fdtdx_comm_boundary_done(ctx_, stream));
+    }
 
 public:
     // stencil.h:385-413; rank/nprocs: the z-slab this process owns (MPI rank/size in the reference)
@@ -103,12 +123,71 @@ public:
     void transferCubeToGPU(const std::string &name, DataType *cpu) { FDTDX_ASSERT(fdtdx_transfer_cube_to_gpu(ctx_, name.c_str(), cpu)); }
     void transferCubeToCPU(DataType *cpu, const std::string &name) { FDTDX_ASSERT(fdtdx_transfer_cube_to_cpu(ctx_, cpu, name.c_str())); }
 
-    // stencil.h:684-768.  `spill` only chose launch bounds in the reference; ignored.
+    // stencil.h:684-768.  `spill` only chose launch bounds in the reference; ignored.  Where the planes next to the
+    // neighbours have already been swept into this cube (propagateHalo{Top,Buttom}Backup since the last exchange), only
+    // the planes between them are left to do.
     void propagate(const std::string &output, const std::string &input, bool spill, const fdtdx_program &prog, void *stream = nullptr)
     {
         (void)spill;
-        FDTDX_ASSERT(fdtdx_propagate(ctx_, output.c_str(), input.c_str(), &prog, stream));
+        if (boundary_of_ == output && (done_lo_ || done_hi_)) {
+            const uint64_t r = prog.kind == FDTDX_STAR ? prog.radius : 1;
+            uint64_t lo = g_.ghost_lo ? g_.ghost_lo : r, hi = g_.ghost_hi ? g_.local_planes - g_.ghost_hi : g_.local_planes - r;
+            if (done_lo_) lo = std::min<uint64_t>(lo + M, hi);
+            if (done_hi_) hi = std::max<uint64_t>(hi - M, lo);
+            FDTDX_ASSERT(fdtdx_propagate_planes(ctx_, output.c_str(), input.c_str(), &prog, lo, hi, stream));
+        } else {
+            FDTDX_ASSERT(fdtdx_propagate(ctx_, output.c_str(), input.c_str(), &prog, stream));
+        }
     }
+    // ---- the multi-rank flow of the drivers' loop (fdtd1.cu:70-78) ---------------------------------------------------
+    // stencil.h:435-438
+    void barrier() { FDTDX_ASSERT(fdtdx_comm_barrier(ctx_)); }
+    // The communicator replaces MPI::Init / COMM_WORLD of stencil.h:389-392: rank 0 makes the id, the launcher hands it on.
+    static fdtdx_comm_id commUniqueId()
+    {
+        fdtdx_comm_id id;
+        FDTDX_ASSERT(fdtdx_comm_unique_id(&id));
+        return id;
+    }
+    void commInit(const fdtdx_comm_id &id) { FDTDX_ASSERT(fdtdx_comm_init(ctx_, &id)); }
+    // all slabs in this process (ranks 0..n-1 in order): copies between them instead of RCCL; two-phase exchanges
+    static void commInitLocal(Stencil *const *slabs, int n)
+    {
+        fdtdx_ctx *h[64];
+        for (int i = 0; i < n && i < 64; i++) h[i] = slabs[i]->ctx_;
+        FDTDX_ASSERT(fdtdx_comm_init_local(h, n < 64 ? n : 64));
+    }
+    // backupCubeHaloBackup / restoreCubeHaloBackup (stencil.h:658-682) copied boundary planes into side buffers and the
+    // received ghost planes back; here ghost planes live in the cube and are received in place: nothing to do.
+    void backupCubeHaloBackup(const std::string &) {}
+    void restoreCubeHaloBackup(const std::string &) {}
+    // propagateHaloTopBackup / ButtomBackup (stencil.h:770-808): the M planes next to the neighbour below (rank-1: "top",
+    // the first planes of the slab) / above.  They are swept straight into the cube, and the point behind them is marked
+    // for the exchange, which therefore does not wait for an interior sweep queued after them.
+    void propagateHaloTopBackup(const std::string &output, const std::string &input, bool spill, const fdtdx_program &prog, void *stream = nullptr)
+    {
+        halo_sweep(output, input, spill, prog, stream, 0);
+    }
+    void propagateHaloButtomBackup(const std::string &output, const std::string &input, bool spill, const fdtdx_program &prog,
+                                   void *stream = nullptr)
+    {
+        halo_sweep(output, input, spill, prog, stream, 1);
+    }
+    // commCubeHaloBackup (stencil.h:649-656) / commCubeHalo (stencil.h:639-647): boundary planes to the neighbours' ghost
+    // planes.  Stream-ordered instead of host-blocking: it returns at once, work queued on `stream` afterwards sees the
+    // ghosts, sync() waits for everything.  (Slabs linked with commInitLocal use exchangeStart / exchangeWait in two phases.)
+    void commCubeHaloBackup(const std::string &name, void *stream = nullptr)
+    {
+        FDTDX_ASSERT(fdtdx_comm_cube_halo(ctx_, name.c_str(), stream));
+        done_lo_ = done_hi_ = false;
+    }
+    void commCubeHalo(const std::string &name, void *stream = nullptr) { commCubeHaloBackup(name, stream); }
+    void exchangeStart(const std::string &name, void *stream = nullptr)
+    {
+        FDTDX_ASSERT(fdtdx_comm_exchange_start(ctx_, name.c_str(), stream));
+        done_lo_ = done_hi_ = false;
+    }
+    void exchangeWait(void *stream = nullptr) { FDTDX_ASSERT(fdtdx_comm_exchange_wait(ctx_, stream)); }
     // propagateHalo{Top,Buttom}Backup (stencil.h:770-808): one step on local planes [z_lo, z_hi) only
     void propagatePlanes(const std::string &output, const std::string &input, const fdtdx_program &prog, uint64_t z_lo, uint64_t z_hi,
                          void *stream = nullptr)

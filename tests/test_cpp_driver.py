@@ -42,6 +42,42 @@ def test_cpp_driver_matches_oracle(oracle_cpu, variant, steps):
     assert crc == [zlib.crc32(a.tobytes()), zlib.crc32(b.tobytes())]
 
 
+LOOP_EXE = os.path.join(ROOT, "examples", "fdtd1_loop")
+
+
+def build_loop():
+    cmd = ["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "fdtd1_loop.cpp"),
+           "-L" + os.path.join(ROOT, "fdtd_amd"), "-lfdtdx", "-Wl,-rpath," + os.path.join(ROOT, "fdtd_amd"),
+           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-pthread", "-o", LOOP_EXE]
+    subprocess.check_call(cmd)
+
+
+def test_multi_rank_loop_compiles_against_the_mirror():
+    """The body of the reference's multi-rank loop (fdtd1.cu:70-78: backupCubeHaloBackup, propagateHalo{Top,Buttom}Backup,
+    sync, propagate, commCubeHaloBackup, restoreCubeHaloBackup, barrier) compiles against include/fdtdx/stencil.hpp."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    build_loop()
+    assert os.path.exists(LOOP_EXE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,radius,steps", [(["local", "2"], 1, 7), (["local", "3"], 4, 3), (["local", "2"], 8, 2),
+                                               (["spmd", "0", "1", "unused-id-file"], 2, 5)])
+def test_multi_rank_loop_matches_oracle(oracle_cpu, tmp_path, args, radius, steps):
+    """The reference's loop on the C++ mirror, slabs exchanging ghost planes inside the library (two and three slabs in one
+    process; one rank through the one-process-per-slab path): the cube it gathers has the CRC-32 of the oracle's."""
+    import zlib
+    if not os.path.exists(LOOP_EXE):
+        build_loop()
+    out = subprocess.run([LOOP_EXE] + args + [str(radius), str(steps)], capture_output=True, text=True, timeout=300, cwd=tmp_path)
+    assert out.returncode == 0, out.stdout + out.stderr
+    crc = int(out.stdout.split("crc32", 1)[1].split()[0], 16)
+    a, b = oracle_cpu.init_mt(192, 160, 256)
+    oracle_cpu.run("star", a, b, steps, M=radius, order=oracle_cpu.ORDER_CHAIN)
+    assert crc == zlib.crc32(a.tobytes())
+
+
 FUNCTOR_EXE = os.path.join(ROOT, "examples", "functor_driver")
 
 
