@@ -348,11 +348,27 @@ def main():
         cs = torch.cuda.current_stream().cuda_stream
         if native:
             # the library's own communicator: rank 0 makes the id, torch.distributed carries its 128 bytes to the others
-            box = [Stencil.commUniqueId() if rank == 0 else None]
+            ok = torch.ones(1, device="cuda")
+            box = [None]
+            if rank == 0:
+                try:
+                    box = [Stencil.commUniqueId()]
+                except Exception as e:
+                    print(f"rank 0: no RCCL id ({e})", file=sys.stderr)
             dist.broadcast_object_list(box, src=0)
-            be.st.commInit(box[0])
-            if a.reserve_cus:
-                be.st.setOption("reserve_cus", a.reserve_cus)
+            try:
+                if box[0] is None:
+                    raise RuntimeError("rank 0 could not make a communicator id")
+                be.st.commInit(box[0])
+                if a.reserve_cus:
+                    be.st.setOption("reserve_cus", a.reserve_cus)
+            except Exception as e:  # every rank must take the same path: agree below
+                print(f"rank {rank}: native exchange unavailable ({e})", file=sys.stderr)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() == 0:
+                native = False
+                a.exchange = "torch"
 
         def loop(k):
             if world == 1:
