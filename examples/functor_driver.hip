@@ -1,6 +1,6 @@
 // functor_driver.hip -- user-written device lambdas through fdtdx/stencil_functor.hpp, checked against
 // the closed programs of the C ABI on the same inputs.
-//   build: hipcc -std=c++17 -O3 --offload-arch=gfx950 -Iinclude examples/functor_driver.hip -Lfdtd_amd -lfdtdx
+//   build: hipcc -std=c++17 -O3 -fno-slp-vectorize --offload-arch=gfx950 -Iinclude examples/functor_driver.hip -Lfdtd_amd -lfdtdx
 //          -Wl,-rpath,$PWD/fdtd_amd -o examples/functor_driver        (fdtd_amd/csrc/Makefile does it)
 //   run:   ./functor_driver        -> one line per case, exit status 0 when every case agrees
 //          ./functor_driver bench  -> throughput of a radius-3 lambda at 512^3 beside the closed program's
@@ -132,9 +132,25 @@ static int bench()
     return 0;
 }
 
+// with "dump <dir>": what the lambdas computed, as raw fp32 [z][y][x] files, for a test to set beside an independent CPU computation
+static const char *g_dump = nullptr;
+static void dump(const char *name, const std::vector<float> &v)
+{
+    if (!g_dump) return;
+    char path[1024];
+    std::snprintf(path, sizeof(path), "%s/%s.f32", g_dump, name);
+    FILE *f = std::fopen(path, "wb");
+    if (!f || std::fwrite(v.data(), 4, v.size(), f) != v.size()) {
+        std::fprintf(stderr, "cannot write %s\n", path);
+        std::exit(1);
+    }
+    std::fclose(f);
+}
+
 int main(int argc, char **argv)
 {
     if (argc > 1 && std::strcmp(argv[1], "bench") == 0) return bench();
+    if (argc > 2 && std::strcmp(argv[1], "dump") == 0) g_dump = argv[2];
     int bad = 0;
     {   // radius-3 star in star mode: registers along z, LDS along y and x
         fdtdx::FunctorStencil<float, nz, ny, nx, 3, true, gpu_size_t, gpu_signed_size_t> st;
@@ -158,6 +174,7 @@ int main(int argc, char **argv)
         st.propagate("q0", "p1", true, fdtdx::star_program(3));
         st.sync();
         bad += compare("star radius 3 (star mode)", fetch(st, "p0"), fetch(st, "q0"));
+        dump("star3", fetch(st, "p0"));
     }
     {   // 13-point stencil in box mode: mixed offsets
         fdtdx::FunctorStencil<float, nz, ny, nx, 1, false, gpu_size_t, gpu_signed_size_t> st;
@@ -185,6 +202,7 @@ int main(int argc, char **argv)
         st.propagate("q0", "p1", true, fdtdx::spc13_program());
         st.sync();
         bad += compare("13-point (box mode)", fetch(st, "p0"), fetch(st, "q0"));
+        dump("spc13", fetch(st, "p0"));
     }
     {   // main.cu's pipeline with lambdas: update with extra arguments, inject, filt, mul
         fdtdx::FunctorStencil<float, nz, ny, nx, 4, true, gpu_size_t, gpu_signed_size_t> st;
@@ -236,6 +254,8 @@ int main(int argc, char **argv)
         st.sync();
         bad += compare("main.cu update+inject+filt", fetch(st, "p0"), fetch(st, "q0"));
         bad += compare("main.cu sum", fetch(st, "sum"), fetch(st, "qsum"));
+        dump("main_p0", fetch(st, "p0"));
+        dump("main_sum", fetch(st, "sum"));
         FDTDX_HIP_ASSERT(hipFree(dev_addr));
     }
     std::printf(bad ? "FAILED\n" : "all cases agree\n");

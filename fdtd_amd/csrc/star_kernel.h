@@ -114,11 +114,7 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
     const unsigned nbn = more_n ? plane_bytes : 0u, nbc = more_c ? plane_bytes : 0u;
     const long long pf = plane_bytes >> 2;
     const __amdgpu_buffer_rsrc_t rn = make_rsrc(pn, nbn);        // plane z+M+PF
-#ifdef FDTDX_EXP_HALO_AHEAD  // timing experiment (wrong results): halo rows fetched from the plane the own rows are fetched from
-    const __amdgpu_buffer_rsrc_t rc = make_rsrc(pn, nbn);
-#else
     const __amdgpu_buffer_rsrc_t rc = make_rsrc(pc + pf, nbc);   // halo of plane z+1
-#endif
     const __amdgpu_buffer_rsrc_t ron = make_rsrc(po + pf, nbc);  // shell components of output plane z+1
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(po, plane_bytes);
     float4 eo_cur[RY], vq_cur[RY], sq_cur[RY];

@@ -23,9 +23,6 @@
 // multiplies and adds, pairs parenthesised as fdtdspc.cu:46-52).
 #pragma once
 #include "tb_kernel.h"
-#ifndef FDTDX_EXP
-#define FDTDX_EXP 0  // timing experiments (wrong results): 1 no loads in the loop, 2 no stores, 3 no second barrier
-#endif
 
 namespace fdtdx {
 
@@ -240,12 +237,10 @@ __global__ __launch_bounds__(NW * 64) void tb_spc_kernel(const TbParams p)
             const __amdgpu_buffer_rsrc_t rm = rsrc_of(p.mid, more ? pz - 1 : -1);
 #pragma unroll
             for (int j = 0; j < RY; j++) {
-#if FDTDX_EXP != 1
 #pragma unroll
                 for (int i = 0; i < RX; i++) nx[j][i] = buf_ld4(rn, goff[j][i]);
                 mvx[j] = buf_ld4(rm, shq[j]);
                 evx[j] = buf_ld4(re, shq[j]);
-#endif
             }
         }
         // publish, level 0: first row @pz and @pz-1, last row @pz-1 and @pz-2; level 1: the same two planes lower
@@ -287,7 +282,7 @@ __global__ __launch_bounds__(NW * 64) void tb_spc_kernel(const TbParams p)
                 constexpr int J = decltype(jt)::value;
 #pragma unroll
                 for (int i = 0; i < RX; i++) {
-                    const unsigned f = flags[J][i], so = (FDTDX_EXP != 2 && (f & 32u)) ? goff[J][i] : OOB;
+                    const unsigned f = flags[J][i], so = (f & 32u) ? goff[J][i] : OOB;
                     // whole quads in one store; quads that straddle the x shell cell by cell, so that `out` keeps its shell
                     buf_st4(ro, (f & 15u) == 15u ? so : OOB, res[i].x, res[i].y, res[i].z, res[i].w);
                     const unsigned sp = (f & 15u) != 15u ? so : OOB;
@@ -305,9 +300,7 @@ __global__ __launch_bounds__(NW * 64) void tb_spc_kernel(const TbParams p)
 #pragma unroll
             for (int i = 0; i < RX; i++) q1[OLD][J][i] = res[i];
         });
-#if FDTDX_EXP != 3
         __syncthreads();  // every wave has read the rows it needs before the next ones are published
-#endif
         // input plane pz+1 takes the place of plane pz-2
 #pragma unroll
         for (int j = 0; j < RY; j++)

@@ -90,3 +90,37 @@ def test_functor_header_lambdas_agree_with_closed_programs():
     out = subprocess.run([FUNCTOR_EXE], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all cases agree" in out.stdout
+
+
+@pytest.mark.gpu
+def test_functor_header_lambdas_agree_with_the_oracle(oracle_cpu, tmp_path):
+    """The same lambdas against the CPU oracle (an independent computation, not another HIP kernel): fdtd3.cu's radius-3
+    lambda in star mode, fdtdspc.cu's 13-point lambda in box mode, main.cu's update / inject / filt / mul lambdas.  The
+    compiler contracts the lambdas' "acc += c*v" as it sees fit, so the comparison is at the tolerance the path is specified
+    to (1e-5 relative; against the field's scale where main.cu's update subtracts the old field), with the device order
+    as the reference."""
+    import numpy as np
+    assert os.path.exists(FUNCTOR_EXE), "build it with `make -C fdtd_amd/csrc`"
+    out = subprocess.run([FUNCTOR_EXE, "dump", str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    nz, ny, nx = 37, 45, 150  # the driver's grid
+    load = lambda name: np.fromfile(os.path.join(tmp_path, name + ".f32"), dtype=np.float32).reshape(nz, ny, nx)
+
+    def close(got, ref, what):
+        scale = np.maximum(np.abs(ref.astype(np.float64)), 0.01 * np.abs(ref).max())
+        err = (np.abs(got.astype(np.float64) - ref.astype(np.float64)) / scale).max()
+        assert err <= 1e-5, (what, err)
+
+    p0, p1 = oracle_cpu.init_mt(nz, ny, nx)
+    ref = p0.copy()
+    oracle_cpu.step("star", ref, p1, M=3, order=oracle_cpu.ORDER_CHAIN)
+    close(load("star3"), ref, "star radius 3")
+    ref = p0.copy()
+    oracle_cpu.step("spc13", ref, p1, order=oracle_cpu.ORDER_CHAIN)
+    close(load("spc13"), ref, "13-point")
+    # main.cu's step: the driver's vel is a second draw of the p0 field, its addresses (i * 2654435761) % cells
+    a, b, vel, total = p0.copy(), p1.copy(), p0.copy(), np.zeros_like(p0)
+    addr = ((np.arange(500, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(nz * ny * nx)).astype(np.uint64)
+    oracle_cpu.main_step(a, b, vel, total, addr, order=oracle_cpu.ORDER_CHAIN)
+    close(load("main_p0"), a, "main.cu update + inject + filt")
+    close(load("main_sum"), total, "main.cu sum")
