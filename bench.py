@@ -426,7 +426,7 @@ def main():
                 probe(nprobe)
                 e1.record(stream)
                 torch.cuda.synchronize()
-                res.update(kernel_us=e0.elapsed_time(e1) * 1e3 / nprobe, kernel_steps=k)
+                res.update(kernel_us=e0.elapsed_time(e1) * 1e3 / nprobe, kernel_steps=k, kernel_launches=nprobe)
             except Exception:  # no such launch for this program: the loop average stands in
                 pass
             if a.standing_start:
@@ -454,12 +454,12 @@ def main():
         # bytes per cell-step: sweeps 8; main 24 (one fused step); yee3d 48 in one launch (72 as two half steps), yee2d 36 as two launches
         bpu = {"composite": BYTES_PER_UPDATE_MAIN, "yee3d": 48.0 if a.temporal else 72.0, "yee2d": 36.0}.get(r["kind"], BYTES_PER_UPDATE)
         if "kernel_us" in r:
-            launch_s, spl = r["kernel_us"] * 1e-6, float(r["kernel_steps"])
+            launch_s, spl, navg = r["kernel_us"] * 1e-6, float(r["kernel_steps"]), r["kernel_launches"]
         else:
             # several ranks (a step is split into boundary-plane and interior launches of the same kernel) and the
             # pipelines with several kernels per step: average over the launches of the timed region
             nlaunch = r["launches"] or steps
-            launch_s, spl = r["ev_ms"] * 1e-3 / nlaunch, steps / nlaunch
+            launch_s, spl, navg = r["ev_ms"] * 1e-3 / nlaunch, steps / nlaunch, nlaunch
         alg = bpu * r["cells_rank"] * spl
         achieved = alg / launch_s * 1e-9
         traffic = None
@@ -471,7 +471,7 @@ def main():
         if ent and world == 1 and not a.grid and ent.get("launch_info") in (None, shape_now):
             traffic = ent.get("hbm_bytes_per_launch")
         out = {"gcells": round(value, 2), "ms_per_step": round(r["dt"] / steps * 1e3, 5), "launch_us": round(launch_s * 1e6, 2),
-               "steps_per_launch": round(spl, 3), "achieved": round(achieved, 1), "frac": round(achieved / PEAK_HBM_GBS, 4),
+               "steps_per_launch": round(spl, 3), "launches": navg, "achieved": round(achieved, 1), "frac": round(achieved / PEAK_HBM_GBS, 4),
                "algorithmic_bytes_per_launch": alg, "traffic": traffic,
                "hbm_achieved": round(traffic / launch_s * 1e-9, 1) if traffic else None,
                "hbm_frac": round(traffic / launch_s * 1e-9 / PEAK_HBM_GBS, 4) if traffic else None,
@@ -517,7 +517,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": t["achieved"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": t["frac"],
                      "traffic": t["traffic"], "hbm_achieved": t["hbm_achieved"], "hbm_frac": t["hbm_frac"],
                      "algorithmic_bytes_per_launch": t["algorithmic_bytes_per_launch"], "steps_per_launch": t["steps_per_launch"],
-                     "launch_us": t["launch_us"]},
+                     "launch_us": t["launch_us"], "launches": t["launches"]},
     }
     if len(names) > 1:
         line["variants"] = table

@@ -14,12 +14,14 @@ for f in glob.glob(f"{d}/trace/*/*_kernel_stats.csv"):
             out["kernel"] = r["Name"]
             out["calls"] = int(r["Calls"])
             out["avg_us"] = float(r["AverageNs"]) / 1e3
-# the same kernel over the timed region only: bench.py's line (trace.log) says how many sweep launches it
-# timed; they are the last ones of the run (the spin-up and warm-up launches before them are slower while
-# the device clocks ramp up, so the all-launch average above sits a few percent higher)
+# the same kernel over the launches bench.py's own launch_us comes from: the run of the dominant kernel that closes the
+# bench (run it with --no-standing-start so that nothing follows); the spin-up and warm-up launches before it are slower
+# while the device clocks ramp up, so the all-launch average above sits a few percent higher
 try:
     line = [l for l in open(f"{d}/trace.log") if l.startswith("{")][-1]
-    timed = int(json.loads(line)["roofline"]["launches"])
+    roof = json.loads(line)["roofline"]
+    # the launches bench.py's launch_us is averaged over: its closing run of the dominant kernel
+    timed = int(roof.get("launches") or max(6, min(60, int(json.loads(line)["steps"]) // max(1, round(roof["steps_per_launch"])))))
     for f in glob.glob(f"{d}/trace/*/*_kernel_trace.csv"):
         durs = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
                 for r in csv.DictReader(open(f)) if r["Kernel_Name"] == out.get("kernel")]
