@@ -344,6 +344,15 @@ def main():
             be.st.initMt("p0", "p1")
         prog = make_program(kind, radius=radius)
         be.st.setOption("temporal", a.temporal)
+        # the two-step loops that hop through a third cube (radius 2; radius 1 under --temporal 2) get it from here, by name:
+        # nothing is allocated inside the timed loop
+        work = None
+        if world == 1 and a.temporal != 0 and kind == "star" and (radius == 2 or (radius == 1 and a.temporal == 2)):
+            be.alloc("work")
+            work = "work"
+        if world == 1 and kind == "jacobi7" and a.temporal == 2:
+            be.alloc("work")
+            work = "work"
         run = SlabRunner(be, ghost, prog, rank, world, exchange="host" if a.rehearse_shared_gpu else "device")
         cs = torch.cuda.current_stream().cuda_stream
         if native:
@@ -374,7 +383,7 @@ def main():
             if world == 1:
                 # one rank: the whole time loop runs inside the library (fdtdx_sweep, the drivers'
                 # loop of fdtd1.cu:68-80), which fuses two steps per launch where it can
-                be.st.sweep("p0", "p1", prog, k, cs)
+                be.st.sweep("p0", "p1", prog, k, cs, work=work)
             elif native:
                 Stencil.run([be.st], "p0", "p1", prog, k, [cs])
             else:
@@ -413,12 +422,13 @@ def main():
             nprobe = max(6, min(60, steps // k))
 
             def probe(cnt):
-                o, i = "p0", "p1"
+                # the hops of the library's own loop: between the two cubes, or (two-step loops with a third cube) between p1 and it
+                o, i = ("work", "p1") if (work and k == 2) else ("p0", "p1")
                 for _ in range(cnt):
                     if k == 1:
                         be.st.propagatePlanes(o, i, prog, lo, hi, cs)
                     else:
-                        be.st.propagateFusedPlanes(o, i, o, prog, k, lo, hi, cs)
+                        be.st.propagateFusedPlanes(o, i, "p0" if (work and k == 2) else o, prog, k, lo, hi, cs)
                     o, i = i, o
             try:
                 probe(2)

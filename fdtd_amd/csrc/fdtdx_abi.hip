@@ -562,20 +562,29 @@ static const TbVariantInfo *pick_tb(const fdtdx_ctx *ctx, const fdtdx_program *p
         ord = golden ? ORD_JACOBI_GOLDEN : ORD_JACOBI_CHAIN;
     else if (prog->kind == FDTDX_SPC13) {
         ord = golden ? ORD_SPC_GOLDEN : ORD_SPC_CHAIN;
-        // the fused 13-point kernel keeps one shell quad per lane and row: rows of exactly 65 quads would put the first
-        // and the last quad of a row (both with a shell cell) into one lane; such grids run single steps
-        if ((ctx->cfg.X + 3) / 4 == 65) return nullptr;
     } else
         return nullptr;
+    // The fused 13-point kernel keeps ONE quad with x shell cells per lane and row.  A lane holds the quads 64 apart, so a
+    // row whose first and last quad (both with a shell cell) are 64 apart (rows of exactly 65 quads) does not fit; such
+    // grids run single steps.
+    const bool shells_fit = prog->kind != FDTDX_SPC13 || (ctx->cfg.X + 3) / 4 != 65;
     const TbVariantInfo *best = nullptr;
     int idx = 0;
     for (int i = 0; i < num_tb_variants(); i++) {
         const TbVariantInfo *v = tb_variant(i);
         if (v->order != ord || v->kt != kt || v->radius != radius) continue;
+        if (v->shells && !shells_fit) continue;
         if (ctx->opt_tb_variant >= 0 ? idx == ctx->opt_tb_variant : !best) best = v;
         idx++;
     }
     return best;
+}
+
+// for the multi-slab loop: is there a fused kernel of kt steps for the program on this grid (one that takes both shell sources by name)?
+bool fdtdx_has_fused(const fdtdx_ctx *ctx, const fdtdx_program *prog, int kt, bool shells)
+{
+    const TbVariantInfo *v = pick_tb(ctx, prog, kt);
+    return v && (!shells || v->shells);
 }
 
 static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const float *in, const float *mid, const fdtdx_program *prog,
@@ -707,7 +716,9 @@ extern "C" int fdtdx_propagate2_planes(fdtdx_ctx *ctx, const char *out, const ch
     return fdtdx_propagate_fused_planes(ctx, out, in, mid, prog, 2, z_lo, z_hi, stream);
 }
 
-extern "C" int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const fdtdx_program *prog, uint32_t steps, void *stream)
+// `work`: a third cube for the two-step loops that need one (nullptr: allocated on first use and kept by the context)
+static int sweep_loop(fdtdx_ctx *ctx, const char *a, const char *b, const char *work, bool may_allocate, const fdtdx_program *prog,
+                      uint32_t steps, void *stream)
 {
     if (!ctx) return fail(FDTDX_ERR_INVALID, "null context");
     if (ctx->cfg.nprocs != 1) return fail(FDTDX_ERR_UNSUPPORTED, "fdtdx_sweep runs whole time loops on one rank only; use propagate + halo exchange per step");
@@ -720,6 +731,12 @@ extern "C" int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const f
     rc = fdtdx_find_cube(ctx, b, &pb);
     if (rc) return rc;
     if (pa == pb) return fail(FDTDX_ERR_INVALID, "sweep needs two different cubes");
+    float *pw = nullptr;
+    if (work) {
+        rc = fdtdx_find_cube(ctx, work, &pw);
+        if (rc) return rc;
+        if (pw == pa || pw == pb) return fail(FDTDX_ERR_INVALID, "the work cube must be a third cube");
+    }
     const fdtdx_geometry &g = ctx->g;
     const uint64_t lo = r, hi = g.local_planes - r;
     // Level t lives in b for even t and in a for odd t (step 0 writes a = f(b)), and so does its shell: even levels see b's
@@ -760,20 +777,24 @@ extern "C" int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const f
         // Two steps per launch hop between b and a third cube c that carries b's shell; a only
         // lends its shell to the skipped odd levels.
         uint32_t pairs = (steps % 2 == 0) ? steps / 2 - 1 : ((steps - 1) / 2) & ~1u;
-        if (pairs > 0) {
+        if (pairs > 0 && !pw) {
             const size_t bytes = g.cube_elems * sizeof(float);
             USE_DEVICE(ctx);
-            if (!ctx->tb_scratch && hipMalloc((void **)&ctx->tb_scratch, bytes) != hipSuccess) {
+            if (!may_allocate) {
+                pairs = 0;  // no third cube named: single steps (same results)
+            } else if (!ctx->tb_scratch && hipMalloc((void **)&ctx->tb_scratch, bytes) != hipSuccess) {
                 // no room for the third cube: run the loop as single steps (same results)
                 (void)hipGetLastError();
                 ctx->tb_scratch = nullptr;
                 pairs = 0;
             }
+            pw = ctx->tb_scratch;
         }
         if (pairs > 0) {
             const size_t bytes = g.cube_elems * sizeof(float);
-            HIP_TRY(hipMemcpyAsync(ctx->tb_scratch, pb, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-            float *cur = pb, *oth = ctx->tb_scratch;
+            USE_DEVICE(ctx);
+            HIP_TRY(hipMemcpyAsync(pw, pb, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            float *cur = pb, *oth = pw;
             for (uint32_t k = 0; k < pairs; k++) {
                 rc = launch_tb(ctx, tb, oth, cur, pa, prog, lo, hi, stream);
                 if (rc) return rc;
@@ -797,6 +818,17 @@ extern "C" int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const f
         if (rc) return rc;
     }
     return FDTDX_OK;
+}
+
+extern "C" int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const fdtdx_program *prog, uint32_t steps, void *stream)
+{
+    return sweep_loop(ctx, a, b, nullptr, true, prog, steps, stream);
+}
+
+extern "C" int fdtdx_sweep_work(fdtdx_ctx *ctx, const char *a, const char *b, const char *work, const fdtdx_program *prog, uint32_t steps,
+                                void *stream)
+{
+    return sweep_loop(ctx, a, b, work, false, prog, steps, stream);
 }
 
 // ---- the composite pipeline of main.cu: sweep, inject, filt, mul ---------------------------------------

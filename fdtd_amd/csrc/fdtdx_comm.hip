@@ -462,8 +462,10 @@ extern "C" int fdtdx_run(fdtdx_ctx *const *ctxs, int n, const char *a, const cha
         const bool multi = ctxs[0]->cfg.nprocs > 1;
         const bool r1 = (prog->kind == FDTDX_STAR && prog->radius == 1) || prog->kind == FDTDX_JACOBI7;
         if (steps >= 4 && want != 0) {
-            if (r1 && want != 2 && (!multi || G >= 3 * r)) kt = 3;                              // straight between the two cubes
-            else if (prog->kind == FDTDX_SPC13 && want != 3 && (!multi || G >= 2 * r)) kt = 2;  // in place via the named shell sources
+            if (r1 && want != 2 && (!multi || G >= 3 * r) && fdtdx_has_fused(ctxs[0], prog, 3, false))
+                kt = 3;  // straight between the two cubes
+            else if (want != 3 && (!multi || G >= 2 * r) && fdtdx_has_fused(ctxs[0], prog, 2, true))
+                kt = 2;  // in place via the named shell sources (13-point, radius-2 star)
         }
     }
     auto each = [&](auto &&f) {

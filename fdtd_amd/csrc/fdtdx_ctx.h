@@ -61,4 +61,6 @@ struct fdtdx_ctx {
     } while (0)
 
 int fdtdx_find_cube(fdtdx_ctx *ctx, const char *name, float **p);
+// is there a fused kernel of kt steps per launch for the program on this context's grid (shells: one that takes both shell sources by name)?
+bool fdtdx_has_fused(const fdtdx_ctx *ctx, const fdtdx_program *prog, int kt, bool shells);
 void fdtdx_comm_release(fdtdx_ctx *ctx);  // called by fdtdx_destroy

@@ -49,9 +49,10 @@ __device__ __forceinline__ void star_rows(float4 (&res)[RY][RX], const float4 (&
                 xs[M + 4 + k] = (i < RX - 1 && lane == 63) ? rt[i + 1][k] : rt[i][k];
             }
             xs[M] = C.x, xs[M + 1] = C.y, xs[M + 2] = C.z, xs[M + 3] = C.w;
-            float a[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) a[k] = c[0] * xs[M + k];
+            // two cells per instruction (v_pk_mul/add/fma_f32), spelled out: cells 0,1 and 2,3 of the quad; per cell the same
+            // operations in the same order as the scalar form
+#define XP(k) f32x2{xs[(k)], xs[(k) + 1]}
+            f32x2 a01 = c[0] * XP(M), a23 = c[0] * XP(M + 2);
 #pragma unroll
             for (int r = 1; r <= M; r++) {
                 // rows t+r and t-r of the tile (t = w*RY + j): wave offset and row inside that wave are constants
@@ -62,24 +63,23 @@ __device__ __forceinline__ void star_rows(float4 (&res)[RY][RX], const float4 (&
                 const float4 Yp = (dwp == 0) ? q[KC][rp][i] : exl[min(w + dwp, NW - 1)][rp][i][lane];
                 const float4 Ym = (dwm == 0) ? q[KC][rm][i] : exl[max(w + dwm, 0)][rm][i][lane];
                 const float4 Zp = q[(KC + r) % QN][j][i], Zm = q[(KC - r + QN) % QN][j][i];
-                const float yp[4] = {Yp.x, Yp.y, Yp.z, Yp.w}, ym[4] = {Ym.x, Ym.y, Ym.z, Ym.w};
-                const float zp[4] = {Zp.x, Zp.y, Zp.z, Zp.w}, zm[4] = {Zm.x, Zm.y, Zm.z, Zm.w};
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
+                auto term = [&](f32x2 acc, float cp, f32x2 vp, float cm, f32x2 vm) {
                     if constexpr (GOLDEN) {  // fdtd2.cu:46-52: (+r, -r) pairs, separate multiplies and adds
-                        a[k] = a[k] + (c[1] * xs[M + k + r] + c[2] * xs[M + k - r]);
-                        a[k] = a[k] + (c[3] * yp[k] + c[4] * ym[k]);
-                        a[k] = a[k] + (c[5] * zp[k] + c[6] * zm[k]);
+                        return acc + (cp * vp + cm * vm);
                     } else {  // fdtd2.cu:66-69: x+r, x-r, y+r, y-r, z+r, z-r, every "+ c*v" fused
-                        a[k] = __builtin_fmaf(c[1], xs[M + k + r], a[k]);
-                        a[k] = __builtin_fmaf(c[2], xs[M + k - r], a[k]);
-                        a[k] = __builtin_fmaf(c[3], yp[k], a[k]);
-                        a[k] = __builtin_fmaf(c[4], ym[k], a[k]);
-                        a[k] = __builtin_fmaf(c[5], zp[k], a[k]);
-                        a[k] = __builtin_fmaf(c[6], zm[k], a[k]);
+                        acc = __builtin_elementwise_fma(f32x2{cp, cp}, vp, acc);
+                        return __builtin_elementwise_fma(f32x2{cm, cm}, vm, acc);
                     }
-                }
+                };
+                a01 = term(a01, c[1], XP(M + r), c[2], XP(M - r));
+                a01 = term(a01, c[3], f32x2{Yp.x, Yp.y}, c[4], f32x2{Ym.x, Ym.y});
+                a01 = term(a01, c[5], f32x2{Zp.x, Zp.y}, c[6], f32x2{Zm.x, Zm.y});
+                a23 = term(a23, c[1], XP(M + 2 + r), c[2], XP(M + 2 - r));
+                a23 = term(a23, c[3], f32x2{Yp.z, Yp.w}, c[4], f32x2{Ym.z, Ym.w});
+                a23 = term(a23, c[5], f32x2{Zp.z, Zp.w}, c[6], f32x2{Zm.z, Zm.w});
             }
+#undef XP
+            const float a[4] = {a01.x, a01.y, a23.x, a23.y};
             res[j][i] = make_float4(a[0], a[1], a[2], a[3]);
         }
     }

@@ -82,6 +82,7 @@ SYMBOLS = {
                                                     ctypes.c_uint64, _vp]),
     "fdtdx_propagate2_planes": (ctypes.c_int, [_vp, _c, _c, _c, _P(Program), ctypes.c_uint64, ctypes.c_uint64, _vp]),
     "fdtdx_sweep": (ctypes.c_int, [_vp, _c, _c, _P(Program), ctypes.c_uint32, _vp]),
+    "fdtdx_sweep_work": (ctypes.c_int, [_vp, _c, _c, _c, _P(Program), ctypes.c_uint32, _vp]),
     "fdtdx_propagate_composite_planes": (ctypes.c_int, [_vp, _c, _c, _c, _P(Composite), ctypes.c_uint64, ctypes.c_uint64, _vp]),
     "fdtdx_propagate_composite": (ctypes.c_int, [_vp, _c, _c, _c, _P(Composite), _vp]),
     "fdtdx_composite_step": (ctypes.c_int, [_vp, _c, _c, _c, _c, _c, _P(Composite), ctypes.c_float, ctypes.c_int64, ctypes.c_int64,

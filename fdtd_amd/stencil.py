@@ -131,10 +131,16 @@ class Stencil:
                                                         shell_odd.encode(), ctypes.byref(program), nsteps, z_lo, z_hi,
                                                         ctypes.c_void_p(stream or 0)))
 
-    def sweep(self, a, b, program, steps, stream=None):
-        """The drivers' whole time loop on one rank (fdtd1.cu:68-80)."""
-        _lib.check(self._L.fdtdx_sweep(self._h, a.encode(), b.encode(), ctypes.byref(program), steps,
-                                       ctypes.c_void_p(stream or 0)))
+    def sweep(self, a, b, program, steps, stream=None, work=False):
+        """The drivers' whole time loop on one rank (fdtd1.cu:68-80).  work=False: the library allocates the third cube
+        the radius-2 two-step loop hops through on first use; work="name": that cube of the pool is used; work=None:
+        no third cube, such programs run single steps (neither of the latter two ever allocates)."""
+        if work is False:
+            _lib.check(self._L.fdtdx_sweep(self._h, a.encode(), b.encode(), ctypes.byref(program), steps,
+                                           ctypes.c_void_p(stream or 0)))
+        else:
+            _lib.check(self._L.fdtdx_sweep_work(self._h, a.encode(), b.encode(), work.encode() if work else None,
+                                                ctypes.byref(program), steps, ctypes.c_void_p(stream or 0)))
 
     # -- the composite pipeline of main.cu -----------------------------------------------------------
     def _owned(self):

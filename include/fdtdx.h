@@ -175,9 +175,18 @@ int fdtdx_propagate2_planes(fdtdx_ctx *ctx, const char *out, const char *in, con
 
 /* The drivers' time loop on one rank (fdtd1.cu:68-80 with nprocs == 1): `steps` ping-pong
  * steps, step 0 writes a = f(b), then the roles swap.  On return cube `a`/`b` hold exactly what
- * the reference's two cubes hold after the same number of steps. */
+ * the reference's two cubes hold after the same number of steps.
+ * Memory: the fused loops of the radius-1 programs (three steps per launch) and of the 13-point program (two steps per
+ * launch, in place) run between the two cubes alone.  The two-step loop of the radius-2 star (and of the radius-1
+ * programs under option "temporal" = 2) hops between b and a THIRD cube of the same size that carries b's shell.
+ * fdtdx_sweep allocates that cube on the first such call (hipMalloc, +50 % footprint, kept until fdtdx_destroy) and runs
+ * single steps, with the same results, if the allocation fails.  fdtdx_sweep_work never allocates: the caller names the
+ * third cube (`work`, any cube of the pool other than a and b; its contents are overwritten), or passes NULL, and the
+ * programs that would need it then run single steps. */
 int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const fdtdx_program *prog, uint32_t steps,
                 void *stream);
+int fdtdx_sweep_work(fdtdx_ctx *ctx, const char *a, const char *b, const char *work, const fdtdx_program *prog,
+                     uint32_t steps, void *stream);
 
 /* Ghost-plane exchange regions (commCubeHalo, stencil.h:639-647): pointer/count of the planes to
  * SEND to (what = 0) or RECEIVE from (what = 1) the neighbour on `side` (0 = rank-1, 1 = rank+1).

@@ -246,6 +246,20 @@ public:
     {
         FDTDX_ASSERT(fdtdx_sweep(ctx_, a.c_str(), b.c_str(), &prog, steps, stream));
     }
+    // the same without any allocation inside the library: `work` names the third cube the radius-2 two-step loop hops
+    // through ("" = none: such programs run single steps)
+    void sweepWork(const std::string &a, const std::string &b, const std::string &work, const fdtdx_program &prog, unsigned steps,
+                   void *stream = nullptr)
+    {
+        FDTDX_ASSERT(fdtdx_sweep_work(ctx_, a.c_str(), b.c_str(), work.empty() ? nullptr : work.c_str(), &prog, steps, stream));
+    }
+    // fused launch with both shell sources named (in-place two-step loops between two cubes; see fdtdx.h)
+    void propagateFusedShells(const std::string &output, const std::string &input, const std::string &shell_even, const std::string &shell_odd,
+                              const fdtdx_program &prog, unsigned nsteps, uint64_t z_lo, uint64_t z_hi, void *stream = nullptr)
+    {
+        FDTDX_ASSERT(fdtdx_propagate_fused_shells(ctx_, output.c_str(), input.c_str(), shell_even.c_str(), shell_odd.c_str(), &prog, nsteps, z_lo,
+                                                  z_hi, stream));
+    }
     // commCubeHalo (stencil.h:639-647): where the planes to send/receive are; the launcher moves them
     std::pair<DataType *, size_t> haloRegion(const std::string &name, int side, int what)
     {

@@ -187,3 +187,29 @@ def test_fused_on_two_slabs_equals_one(oracle_cpu, G, kind, steps, R):
     for name, got, ref in (("p0", got0, a), ("p1", got1, b)):
         bad = np.argwhere(got.view(np.uint32) != ref.view(np.uint32))
         assert len(bad) == 0, f"{name}: {len(bad)} cells differ, first {bad[:4].tolist()} last {bad[-2:].tolist()}"
+
+
+@pytest.mark.parametrize("work", ["w", None], ids=["named-third-cube", "no-third-cube"])
+@pytest.mark.parametrize("steps", [6, 9])
+def test_sweep_work_takes_the_third_cube_by_name(oracle_cpu, steps, work):
+    """fdtdx_sweep_work: the radius-2 two-step loop hops through a cube the caller names (no allocation inside the
+    library); without one the loop runs single steps.  Same bits either way."""
+    Z, Y, X, M = 17, 61, 509, 2
+    a, b = oracle_cpu.init_mt(Z, Y, X)
+    ca, cb = a.copy(), b.copy()
+    oracle_cpu.run("star", ca, cb, steps, M=M)
+    with Stencil(Z, Y, X, M) as st:
+        for name in ("p0", "p1", "w"):
+            st.mallocCube(name)
+        st.transferCubeToGPU("p0", a)
+        st.transferCubeToGPU("p1", b)
+        st.sweep("p0", "p1", make_program("star", radius=M), steps, work=work)
+        st.sync()
+        ga, gb = np.empty_like(a), np.empty_like(b)
+        st.transferCubeToCPU(ga, "p0")
+        st.transferCubeToCPU(gb, "p1")
+        info = st.lastLaunchInfo()
+        with pytest.raises(Exception):
+            st.sweep("p0", "p1", make_program("star", radius=M), steps, work="p1")
+    assert ("fused2" in info) == (work is not None), info
+    assert np.array_equal(ga.view(np.uint32), ca.view(np.uint32)) and np.array_equal(gb.view(np.uint32), cb.view(np.uint32)), info
