@@ -138,7 +138,7 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=1000, help="timed steps (1000: the drivers' own run, fdtd1.cu:68)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--variant", default="config3", choices=["config3"] + sorted(VARIANTS),
                     help="config3 (default): fdtd1..8 + fdtdspc + jacobi, headline = the slowest fdtdN")

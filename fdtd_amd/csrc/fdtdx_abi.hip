@@ -412,8 +412,10 @@ static void default_shape(int kind, int r, int nq, int *tq, int *ly, int *ry)
     }
 }
 
+// [z2_lo, z2_hi): a second plane range swept by the same launch (empty: none)
 static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx_program *prog, uint64_t z_lo, uint64_t z_hi, void *stream,
-                        const fdtdx_composite *comp = nullptr, const float *vel = nullptr, float *sum = nullptr, const int64_t *sel = nullptr)
+                        const fdtdx_composite *comp = nullptr, const float *vel = nullptr, float *sum = nullptr, const int64_t *sel = nullptr,
+                        uint64_t z2_lo = 0, uint64_t z2_hi = 0)
 {
     int r;
     int rc;
@@ -430,7 +432,12 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
     const fdtdx_geometry &g = ctx->g;
     if (z_lo < (uint64_t)r || z_hi > g.local_planes - r || z_lo > z_hi)
         return fail(FDTDX_ERR_INVALID, "plane range [%llu,%llu) outside [%d,%llu)", (unsigned long long)z_lo, (unsigned long long)z_hi, r, (unsigned long long)(g.local_planes - r));
-    if (z_lo == z_hi) return FDTDX_OK;
+    if (z2_lo < z2_hi && (z2_lo < z_hi || z2_hi > g.local_planes - r))
+        return fail(FDTDX_ERR_INVALID, "second plane range [%llu,%llu) must lie behind the first and inside the cube", (unsigned long long)z2_lo, (unsigned long long)z2_hi);
+    if (z_lo == z_hi) {  // only the second range has planes
+        if (z2_lo >= z2_hi) return FDTDX_OK;
+        z_lo = z2_lo, z_hi = z2_hi, z2_lo = z2_hi = 0;
+    }
     if (out == in) return fail(FDTDX_ERR_INVALID, "sweep cannot run in place");
 
     SweepParams p;
@@ -492,13 +499,14 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
     const int nq = (p.nx + 3) / 4;                      // quads that hold logical cells
     const int rows = p.ny - 2 * r;                      // computed rows
     const int gx = (nq + tq - 1) / tq, gy = (rows + ly * ry - 1) / (ly * ry);
-    const long long nz = (long long)(z_hi - z_lo);
+    const long long n2 = z2_lo < z2_hi ? (long long)(z2_hi - z2_lo) : 0;
+    const long long nz = std::max<long long>((long long)(z_hi - z_lo), n2);  // chunks are sized for the longer range
     long long chunks = ctx->opt_zchunks;
     if (chunks <= 0) {
         // one workgroup per CU (256 CUs) measured fastest: every extra z chunk re-reads 2r planes
         // to fill its queue, so split z only as far as needed to cover the chip, and keep the
         // fill below ~1/6 of a chunk
-        const long long tiles = (long long)gx * gy;
+        const long long tiles = (long long)gx * gy * (n2 ? 2 : 1);
         const long long cus = std::max<long long>(1, 256 - ctx->opt_reserve_cus);
         chunks = std::max<long long>(1, cus / tiles);  // never more workgroups than CUs: a second round would run nearly empty
         if (threads <= 256) chunks *= 2;  // small workgroups: two per CU
@@ -507,7 +515,9 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
     }
     chunks = std::max<long long>(1, std::min(chunks, nz));
     p.zchunk = (int)((nz + chunks - 1) / chunks);
-    const int gz = (int)((nz + p.zchunk - 1) / p.zchunk);
+    p.gz1 = (int)(((long long)(z_hi - z_lo) + p.zchunk - 1) / p.zchunk);
+    p.z_lo2 = (int)z2_lo, p.z_hi2 = (int)z2_hi;
+    const int gz = p.gz1 + (int)((n2 + p.zchunk - 1) / p.zchunk);
     if ((long long)gx * gy * gz > 0x7fffffffLL) return fail(FDTDX_ERR_UNSUPPORTED, "grid too large (%d,%d,%d)", gx, gy, gz);
 
     p.gx = gx, p.gy = gy, p.gz = gz;
@@ -588,10 +598,13 @@ bool fdtdx_has_fused(const fdtdx_ctx *ctx, const fdtdx_program *prog, int kt, bo
 }
 
 static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const float *in, const float *mid, const fdtdx_program *prog,
-                     uint64_t z_lo, uint64_t z_hi, void *stream, const float *even = nullptr)
+                     uint64_t z_lo, uint64_t z_hi, void *stream, const float *even = nullptr, uint64_t z2_lo = 0, uint64_t z2_hi = 0)
 {
     const fdtdx_geometry &g = ctx->g;
-    if (z_lo >= z_hi) return FDTDX_OK;
+    if (z_lo >= z_hi) {  // only the second range (if any) has planes
+        if (z2_lo >= z2_hi) return FDTDX_OK;
+        z_lo = z2_lo, z_hi = z2_hi, z2_lo = z2_hi = 0;
+    }
     USE_DEVICE(ctx);
     TbParams p;
     p.in = in, p.mid = mid, p.out = out;
@@ -627,7 +640,9 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
             }
         if (narrow) p.gx = gx_full - 1;
     }
-    const long long nz = p.z_hi - p.z_lo;
+    const long long n1 = p.z_hi - p.z_lo, n2 = z2_lo < z2_hi ? (long long)(z2_hi - z2_lo) : 0;
+    const long long nz = std::max(n1, n2);  // chunks are sized for the longer range
+    p.z_lo2 = (int)z2_lo, p.z_hi2 = (int)z2_hi;
     auto launch_part = [&](const TbVariantInfo *k, TbParams q) -> int {
         long long chunks = ctx->opt_tb_zchunks;
         if (chunks <= 0) {
@@ -635,7 +650,7 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
             // ceil(N/256) rounds of the 256 CUs, and every chunk pays for filling its queues (the planes a
             // launch reaches beyond its range are re-read, plus start-up: about 6 planes' worth in all, from
             // timings at 512^3 and 1024^3): take the chunk count with the best product of the two efficiencies.
-            const long long tiles = (long long)q.gx * q.gy;
+            const long long tiles = (long long)q.gx * q.gy * (n2 ? 2 : 1);
             const long long cus = std::max<long long>(1, 256 - ctx->opt_reserve_cus);
             double best = -1.0;
             chunks = 1;
@@ -647,7 +662,8 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
         }
         chunks = std::max<long long>(1, std::min(chunks, nz));
         q.zchunk = (int)((nz + chunks - 1) / chunks);
-        q.gz = (int)((nz + q.zchunk - 1) / q.zchunk);
+        q.gz1 = (int)((n1 + q.zchunk - 1) / q.zchunk);
+        q.gz = q.gz1 + (int)((n2 + q.zchunk - 1) / q.zchunk);
         if ((long long)q.gx * q.gy * q.gz > 0x7fffffffLL) return fail(FDTDX_ERR_UNSUPPORTED, "grid too large");
         k->launch(q, dim3((unsigned)(q.gx * q.gy * q.gz)), (hipStream_t)stream);
         HIP_TRY(hipGetLastError());
@@ -671,7 +687,7 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
 // out = f^nsteps(in*), in* = in with the shell of `even`; the odd intermediate levels take their shell from `odd`,
 // the even ones from `even`; the shell of `out` is not written
 static int fused_launch_checked(fdtdx_ctx *ctx, const char *out, const char *in, const char *even, const char *odd, const fdtdx_program *prog,
-                                uint32_t nsteps, uint64_t z_lo, uint64_t z_hi, void *stream)
+                                uint32_t nsteps, uint64_t z_lo, uint64_t z_hi, void *stream, uint64_t z2_lo = 0, uint64_t z2_hi = 0)
 {
     if (!ctx) return fail(FDTDX_ERR_INVALID, "null context");
     int r;
@@ -695,7 +711,24 @@ static int fused_launch_checked(fdtdx_ctx *ctx, const char *out, const char *in,
     const uint64_t need_lo = g.ghost_lo ? reach : r, need_hi = g.ghost_hi ? reach : r;
     if ((g.ghost_lo && g.ghost_lo < reach) || (g.ghost_hi && g.ghost_hi < reach) || z_lo < need_lo || z_hi > g.local_planes - need_hi || z_lo > z_hi)
         return fail(FDTDX_ERR_INVALID, "fused plane range [%llu,%llu) needs %llu ghost planes towards a neighbour", (unsigned long long)z_lo, (unsigned long long)z_hi, (unsigned long long)reach);
-    return launch_tb(ctx, tb, po, pi, pm, prog, z_lo, z_hi, stream, pe);
+    if (z2_lo < z2_hi && (z2_lo < z_hi || z2_hi > g.local_planes - need_hi))
+        return fail(FDTDX_ERR_INVALID, "second fused plane range [%llu,%llu) must lie behind the first and inside the cube", (unsigned long long)z2_lo, (unsigned long long)z2_hi);
+    return launch_tb(ctx, tb, po, pi, pm, prog, z_lo, z_hi, stream, pe, z2_lo, z2_hi);
+}
+
+// One launch over two plane ranges (the planes next to either neighbour of a slab): for the multi-slab step.
+int fdtdx_propagate_two_ranges(fdtdx_ctx *ctx, const char *out, const char *in, const fdtdx_program *prog, uint64_t z_lo, uint64_t z_hi,
+                               uint64_t z2_lo, uint64_t z2_hi, void *stream)
+{
+    float *po, *pi;
+    int rc;
+    if ((rc = fdtdx_find_cube(ctx, out, &po)) || (rc = fdtdx_find_cube(ctx, in, &pi))) return rc;
+    return launch_sweep(ctx, po, pi, prog, z_lo, z_hi, stream, nullptr, nullptr, nullptr, nullptr, z2_lo, z2_hi);
+}
+int fdtdx_propagate_fused_two_ranges(fdtdx_ctx *ctx, const char *out, const char *in, const char *even, const char *odd, const fdtdx_program *prog,
+                                     uint32_t nsteps, uint64_t z_lo, uint64_t z_hi, uint64_t z2_lo, uint64_t z2_hi, void *stream)
+{
+    return fused_launch_checked(ctx, out, in, even, odd, prog, nsteps, z_lo, z_hi, stream, z2_lo, z2_hi);
 }
 
 extern "C" int fdtdx_propagate_fused_planes(fdtdx_ctx *ctx, const char *out, const char *in, const char *mid, const fdtdx_program *prog,
@@ -1306,6 +1339,8 @@ extern "C" int fdtdx_set_option(fdtdx_ctx *ctx, const char *key, int64_t value)
         ctx->opt_tb_variant = value;
     else if (!strcmp(key, "tb_zchunks"))
         ctx->opt_tb_zchunks = value;
+    else if (!strcmp(key, "boundary_stream"))
+        ctx->opt_boundary_stream = value != 0;
     else if (!strcmp(key, "reserve_cus"))
         ctx->opt_reserve_cus = std::max<int64_t>(0, std::min<int64_t>(value, 255));
     else

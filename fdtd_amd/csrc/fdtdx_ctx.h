@@ -40,6 +40,7 @@ struct fdtdx_ctx {
     int64_t opt_temporal = 1;          // fuse two steps per launch where a fused kernel exists
     int64_t opt_tb_variant = -1;       // shape of the fused kernel, -1 = auto
     int64_t opt_tb_zchunks = 0;
+    int64_t opt_boundary_stream = 0;   // 1: a multi-rank step's boundary-plane sweep runs on a stream of its own, beside the interior sweep
     int64_t opt_reserve_cus = 0;       // CUs a sweep launch leaves without a workgroup (room for the exchange's kernels)
     float *tb_scratch = nullptr;       // third cube of the fused time loop (owned)
     float *saved_sum = nullptr;        // fdtdx_composite_step: sum values at the injection addresses
@@ -63,4 +64,9 @@ struct fdtdx_ctx {
 int fdtdx_find_cube(fdtdx_ctx *ctx, const char *name, float **p);
 // is there a fused kernel of kt steps per launch for the program on this context's grid (shells: one that takes both shell sources by name)?
 bool fdtdx_has_fused(const fdtdx_ctx *ctx, const fdtdx_program *prog, int kt, bool shells);
+// one launch over two plane ranges, the second behind the first (either may be empty)
+int fdtdx_propagate_two_ranges(fdtdx_ctx *ctx, const char *out, const char *in, const fdtdx_program *prog, uint64_t z_lo, uint64_t z_hi,
+                               uint64_t z2_lo, uint64_t z2_hi, void *stream);
+int fdtdx_propagate_fused_two_ranges(fdtdx_ctx *ctx, const char *out, const char *in, const char *even, const char *odd, const fdtdx_program *prog,
+                                     uint32_t nsteps, uint64_t z_lo, uint64_t z_hi, uint64_t z2_lo, uint64_t z2_hi, void *stream);
 void fdtdx_comm_release(fdtdx_ctx *ctx);  // called by fdtdx_destroy

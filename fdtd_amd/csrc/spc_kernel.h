@@ -46,8 +46,9 @@ __global__ __launch_bounds__(TQ *LY) void spc13_sweep_kernel(const SweepParams p
     logical_tile(p, bx, by, bz);
     const int q0 = bx * TQ;
     const int y0 = 1 + by * CY;
-    const int zs = p.z_lo + bz * p.zchunk;
-    const int ze = min(zs + p.zchunk, p.z_hi);
+    int zs, ze, zrange_end;
+    chunk_planes(p, bz, zs, ze, zrange_end);
+    (void)zrange_end;
     if (zs >= ze) return;
 
     const int qx = q0 + tx;

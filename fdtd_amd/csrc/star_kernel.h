@@ -298,8 +298,8 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
     logical_tile(p, bx, by, bz);
     const int q0 = bx * TQ;           // first quad of the tile
     const int y0 = p.h + by * CY;     // first computed row of the tile
-    const int zs = p.z_lo + bz * p.zchunk;
-    const int ze = min(zs + p.zchunk, p.z_hi);
+    int zs, ze, zrange_end;
+    chunk_planes(p, bz, zs, ze, zrange_end);
     if (zs >= ze) return;                     // whole workgroup leaves together
 
     Lane<RY, NHK> L;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
     float4 eo[RY];
     float4 hv[NHK];
     // q[k] = plane zs-M+k for k < QT-1; slot QT-1 is loaded by the first step
-    const int zlast = p.z_hi + M;  // one past the last plane the sweep may read
+    const int zlast = zrange_end + M;  // one past the last plane the sweep may read
 #pragma unroll
     for (int j = 0; j < RY; j++) {
 #pragma unroll

@@ -30,6 +30,7 @@ struct SweepParams {
     int z_lo, z_hi;   // local planes [z_lo, z_hi) to update
     int zchunk;       // planes marched by one workgroup
     int gx, gy, gz;   // logical grid of tiles: x tiles, y tiles, z chunks (launched as gx*gy*gz blocks in 1-D)
+    int gz1, z_lo2, z_hi2;  // z chunks gz1 .. gz-1 belong to a second plane range [z_lo2, z_hi2) (gz1 == gz: there is none)
     float c[13];
     // composite update only (main.cu): second input cube, global z of local plane 0, and the
     // constants {cz, cy, cx, snum, sden, wx, wy, wz} as doubles
@@ -117,6 +118,18 @@ __device__ __forceinline__ void logical_tile(const SweepParams &p, int &bx, int 
     const int t = lb / p.gx;
     by = t % p.gy;
     bz = t / p.gy;
+}
+
+// The planes [zs, ze) of z chunk bz, and the end of the plane range it belongs to.  A launch covers one plane range or
+// two (the planes next to either neighbour of a slab, swept ahead of the interior in one launch).
+template <class P>
+__device__ __forceinline__ void chunk_planes(const P &p, int bz, int &zs, int &ze, int &range_end)
+{
+    const bool second = bz >= p.gz1;
+    const int lo = second ? p.z_lo2 : p.z_lo;
+    range_end = second ? p.z_hi2 : p.z_hi;
+    zs = lo + (second ? bz - p.gz1 : bz) * p.zchunk;
+    ze = min(zs + p.zchunk, range_end);
 }
 
 // Compile-time loop: f(PhaseTag<PH>{}) for PH in [PH, N), used to unroll z loops whose register

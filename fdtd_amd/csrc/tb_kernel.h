@@ -47,6 +47,7 @@ struct TbParams {
     int z_lo, z_hi;    // local output planes [z_lo, z_hi); planes z_lo-2 .. z_hi+1 must exist or be global shell
     int zchunk;
     int gx, gy, gz;    // x tiles, y tiles, z chunks (1-D launch of gx*gy*gz workgroups)
+    int gz1, z_lo2, z_hi2;  // z chunks gz1 .. gz-1 belong to a second plane range [z_lo2, z_hi2) (gz1 == gz: there is none)
     int qstep, qbase;  // x tile bx loads quads [qbase + bx*qstep, +64*RX); one tile: qbase 0, else -1 (see kernel)
     int xt;            // rows are cut into x tiles (possibly launched separately): a tile does not store its two outermost quads
     float c[13];
@@ -152,8 +153,9 @@ __global__ __launch_bounds__(NW * 64) void tb_r1_kernel(const TbParams p)
     // cell reaches KT <= 4 cells, i.e. never beyond the adjacent quad) and is stored by the next tile.
     const int tq0 = p.qbase + bx * p.qstep;
     const bool xtiled = p.xt != 0;
-    const int zs = p.z_lo + bz * p.zchunk;
-    const int ze = min(zs + p.zchunk, p.z_hi);
+    int zs, ze, zrange_end;
+    chunk_planes(p, bz, zs, ze, zrange_end);
+    (void)zrange_end;
     if (zs >= ze) return;
     const int yt0 = 1 - KT + by * CYO;  // first row the tile loads (may be negative)
     const int yown0 = yt0 + KT, yown1 = yown0 + CYO;

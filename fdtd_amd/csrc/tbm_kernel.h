@@ -106,8 +106,9 @@ __global__ __launch_bounds__(NW * 64) void tb_rm_kernel(const TbParams p)
     }
     const int tq0 = p.qbase + bx * p.qstep;
     const bool xtiled = p.xt != 0;
-    const int zs = p.z_lo + bz * p.zchunk;
-    const int ze = min(zs + p.zchunk, p.z_hi);
+    int zs, ze, zrange_end;
+    chunk_planes(p, bz, zs, ze, zrange_end);
+    (void)zrange_end;
     if (zs >= ze) return;
     const int yt0 = M - KT * M + by * CYO;  // first row the tile loads (may be negative)
     const int yown0 = yt0 + KT * M, yown1 = yown0 + CYO;

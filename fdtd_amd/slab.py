@@ -17,8 +17,8 @@ staging copies.  torch.distributed's "nccl" backend is RCCL on ROCm: sends and r
 RCCL's own HIP stream, ordered after the boundary sweep and overlapped with the interior sweep.
 The same code runs on CPU tensors over "gloo" (tests), with the sweep supplied by the caller.
 
-Both ping-pong cubes are exchanged every step, which is the decomposition-independent update
-(the pattern of main.cu:151-168, not the single-cube shortcut of fdtd1.cu:70-77).
+Every step exchanges the cube it has just written (fdtd1.cu:70-77 does the same); since both ping-pong cubes
+take that role in turn, the ghost planes of both stay current and the update does not depend on the decomposition.
 """
 import ctypes
 

@@ -246,9 +246,10 @@ int fdtdx_run(fdtdx_ctx *const *ctxs, int n, const char *a, const char *b, const
  *                                                         + wz*SUM_r(Z+r + Z-r)) - out
  * with z, y, x the GLOBAL cell coordinates and C, X.., Y.., Z.. cells of `in`.  FDTDX_ORDER_GOLDEN
  * evaluates it as the host loop does (double constants, double arithmetic on float pair sums, one
- * rounding); FDTDX_ORDER_CHAIN as the device lambda (float constants, scal = (float)(num/den), FMAs). */
+ * rounding); FDTDX_ORDER_CHAIN as the device lambda (float constants, scal = (float)(num/den), FMAs).
+ * Kernels are compiled for radius 4, the only radius main.cu uses; any other radius returns FDTDX_ERR_UNSUPPORTED. */
 typedef struct fdtdx_composite {
-    uint32_t radius, order;
+    uint32_t radius, order; /* radius: 4 */
     double cz, cy, cx, scal_num, scal_den, wx, wy, wz;
 } fdtdx_composite;
 /* propagate(out, in, spill, prop_kernel, getCube("vel"), scal) of main.cu:160 on local planes [z_lo, z_hi)
@@ -331,7 +332,10 @@ int fdtdx_yee2d_steps(int device, float *ex, float *ey, float *hz, uint64_t nx, 
  * "variant" (tile-shape index, -1 = auto), "temporal" (time steps fdtdx_sweep fuses per launch where
  * a fused kernel exists: 1 = as many as there is a kernel for, 2, 3, or 0 = one launch per step),
  * "tb_variant" / "tb_zchunks" (shape and z-chunks of the fused kernel), "reserve_cus" (CUs a sweep launch leaves
- * without a workgroup when it sizes its grid: room for the exchange's kernels beside an interior sweep). */
+ * without a workgroup when it sizes its grid: room for the exchange's kernels beside an interior sweep),
+ * "boundary_stream" (0, default: fdtdx_step_begin / fdtdx_hop_begin queue the boundary-plane sweep in the caller's
+ * stream, ahead of the interior sweep; 1: on a stream of the library's own, beside it -- measured slower where the
+ * interior sweep fills every CU, because the boundary sweep and the exchange behind it then wait for CUs). */
 int fdtdx_set_option(fdtdx_ctx *ctx, const char *key, int64_t value);
 /* Describes the kernels the last sweeps launched (tile shape, grid, LDS; the last fused launch if
  * any; launches issued so far), for logs and bench. */
