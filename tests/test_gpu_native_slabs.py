@@ -65,6 +65,27 @@ def test_local_slabs_equal_undecomposed_loop(oracle_cpu, kind, R, ghost, n, step
         assert len(bad) == 0, f"{name}: {len(bad)} cells differ, first {bad[:3].tolist()} ({info})"
 
 
+@pytest.mark.parametrize("kind,R,ghost,steps", [("star", 4, 4, 4), ("star", 1, 3, 8), ("spc13", 1, 2, 10)])
+def test_boundary_stream_option(oracle_cpu, kind, R, ghost, steps):
+    """The same loop with the boundary-plane sweep on the library's own stream, beside the interior sweep."""
+    n = 3
+    Z, Y, X = 20 * n + 2 * ghost, 41, 200
+    a, b = oracle_cpu.init_mt(Z, Y, X)
+    prog = make_program(kind, radius=R)
+    slabs = make_slabs(Z, Y, X, ghost, n, {"p0": a, "p1": b})
+    for s in slabs:
+        s.setOption("boundary_stream", 1)
+    Stencil.commInitLocal(slabs)
+    Stencil.run(slabs, "p0", "p1", prog, steps, None)
+    torch.cuda.synchronize()
+    got0 = np.concatenate([s.downloadOwned("p0") for s in slabs], axis=0)
+    got1 = np.concatenate([s.downloadOwned("p1") for s in slabs], axis=0)
+    for s in slabs:
+        s.close()
+    oracle_cpu.run(kind, a, b, steps, M=R, order=oracle_cpu.ORDER_CHAIN)
+    assert np.array_equal(got0.view(np.uint32), a.view(np.uint32)) and np.array_equal(got1.view(np.uint32), b.view(np.uint32))
+
+
 def test_local_step_by_step_with_marked_boundary(oracle_cpu):
     """The drivers' own order of calls (fdtd1.cu:70-78): boundary sweeps, then the whole interior queued, then the exchange --
     which still only waits for the boundary sweeps, marked with commBoundaryDone."""
