@@ -137,6 +137,41 @@ def test_two_slabs_equal_one(kind, M):
     assert np.array_equal(got1.view(np.uint32), ref1.view(np.uint32))
 
 
+@pytest.mark.parametrize("kind,R,ghost,steps,n", [("star", 4, 4, 3, 2), ("star", 1, 3, 8, 4), ("spc13", 1, 2, 6, 2), ("star", 8, 8, 2, 8)])
+def test_config4_grid_on_slabs_equals_undecomposed(kind, R, ghost, steps, n):
+    """The 2048 x 1024 x 1024 grid of the multi-GPU configuration (2^31 cells, cubes of 2.2e9 elements) cut into n z-slabs
+    that run the library's own multi-slab loop in this one process on the one GPU (ghost planes exchanged by device copies,
+    fused hops where the ghost depth allows): every owned plane equals the undecomposed run bit for bit."""
+    Z, Y, X = 2048, 1024, 1024
+    prog = make_program(kind, radius=R)
+    gen = torch.Generator(device="cuda").manual_seed(19950918)
+    full = HipSlabBackend(Z, Y, X, ghost, 0, 1, 0)
+    init = {}
+    for name in ("p0", "p1"):
+        full.alloc(name).uniform_(generator=gen)
+        init[name] = full.bufs[name].clone()
+    slabs = [HipSlabBackend(Z, Y, X, ghost, r, n, 0) for r in range(n)]
+    P = int(full.g.plane)
+    for be in slabs:
+        lo, cnt = int(be.g.first_global), int(be.g.local_planes)
+        for name in ("p0", "p1"):
+            be.alloc(name).copy_(init[name][lo * P:(lo + cnt) * P])
+    del init
+    Stencil.run([full.st], "p0", "p1", prog, steps)
+    Stencil.commInitLocal([be.st for be in slabs])
+    Stencil.run([be.st for be in slabs], "p0", "p1", prog, steps)
+    torch.cuda.synchronize()
+    info = slabs[0].st.lastLaunchInfo()
+    for be in slabs:
+        first, glo, own = int(be.g.first_global), int(be.g.ghost_lo), int(be.g.owned_planes)
+        for name in ("p0", "p1"):
+            got = be.bufs[name][glo * P:(glo + own) * P].view(torch.int32)
+            ref = full.bufs[name][(first + glo) * P:(first + glo + own) * P].view(torch.int32)
+            assert torch.equal(got, ref), (name, first, info)
+    for be in slabs + [full]:
+        be.st.close()
+
+
 @pytest.mark.parametrize("M", [1, 4, 8])
 def test_thousand_step_value_classes(oracle_cpu, M):
     """The drivers' step count (1000, fdtd1.cu:68) on a reduced grid the oracle can follow: identical zero / denormal /
