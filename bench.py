@@ -152,6 +152,9 @@ def main():
                     help="untimed device spin-up before the warm-up steps (fields restored afterwards); 0 = none")
     ap.add_argument("--reserve-cus", type=int, default=0,
                     help="N > 1, native exchange: CUs the sweep launches leave free for the exchange's kernels")
+    ap.add_argument("--order", default="chain", choices=["chain", "golden"],
+                    help="arithmetic order of the sweeps: chain = the device lambdas' (every + c*v one FMA), golden = the host loops' "
+                         "(separate IEEE multiplies and adds: the order the reference's compiled loops pin bit for bit)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-standing-start", dest="standing_start", action="store_false",
                     help="skip the extra 1000-step run from a standing start (one rank, sweep variants)")
@@ -169,7 +172,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from fdtd_amd import Stencil, make_program
+    from fdtd_amd import Stencil, make_program, ORDER_CHAIN, ORDER_GOLDEN
     from fdtd_amd.slab import HipSlabBackend, SlabRunner
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -342,7 +345,7 @@ def main():
             be.st.initJacobi("p1")
         else:
             be.st.initMt("p0", "p1")
-        prog = make_program(kind, radius=radius)
+        prog = make_program(kind, radius=radius, order=ORDER_GOLDEN if a.order == "golden" else ORDER_CHAIN)
         be.st.setOption("temporal", a.temporal)
         # the two-step loops that hop through a third cube (radius 2; radius 1 under --temporal 2) get it from here, by name:
         # nothing is allocated inside the timed loop
@@ -522,7 +525,7 @@ def main():
         "metric": "cell-updates/sec", "value": t["gcells"], "unit": "Gcell/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": t["ms_per_step"],
         "higher_is_better": True, "scaling": "strong" if fixed else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": workload, "grid": grid, "radius": r["radius"], "parallelism": f"zslab{world}", "kernel": t["kernel"],
+        "config": {"workload": workload, "grid": grid, "radius": r["radius"], "parallelism": f"zslab{world}", "order": a.order, "kernel": t["kernel"],
                    "spinup_ms": a.spinup_ms},
         "roofline": {"bound": "hbm", "achieved": t["achieved"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": t["frac"],
                      "traffic": t["traffic"], "hbm_achieved": t["hbm_achieved"], "hbm_frac": t["hbm_frac"],
