@@ -427,6 +427,9 @@ def main():
             def probe(cnt):
                 # the hops of the library's own loop: between the two cubes, or (two-step loops with a third cube) between p1 and it
                 o, i = ("work", "p1") if (work and k == 2) else ("p0", "p1")
+                if k == 1:  # single steps: the library's loop itself (it keeps strips with the shell components of partly stored quads beside the cubes)
+                    be.st.sweep("p0", "p1", prog, cnt, cs, work=work)
+                    return
                 for _ in range(cnt):
                     if k == 1:
                         be.st.propagatePlanes(o, i, prog, lo, hi, cs)
@@ -434,7 +437,7 @@ def main():
                         be.st.propagateFusedPlanes(o, i, "p0" if (work and k == 2) else o, prog, k, lo, hi, cs)
                     o, i = i, o
             try:
-                probe(2)
+                probe(8)
                 e0.record(stream)
                 probe(nprobe)
                 e1.record(stream)

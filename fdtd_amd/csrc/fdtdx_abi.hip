@@ -153,6 +153,12 @@ extern "C" int fdtdx_create(const fdtdx_config *cfg, fdtdx_ctx **out)
     // set-up of the static scratch for this device (device `dev` is current here); a failure is kept for
     // fdtdx_composite_step_static to report, every other entry point works without the array
     if (scratch_address(dev, &c->static_scratch) != FDTDX_OK) c->static_scratch = nullptr;
+    // two strips of two quads per row for the time loops (0.4 % of a cube each; the loops do without them if there is no room)
+    for (int i = 0; i < 2; i++)
+        if (hipMalloc((void **)&c->shell_strip[i], c->g.local_planes * c->cfg.Y * 8 * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            c->shell_strip[i] = nullptr;
+        }
     *out = c;
     return FDTDX_OK;
 }
@@ -166,6 +172,8 @@ extern "C" int fdtdx_destroy(fdtdx_ctx *ctx)
         if (kv.second.owned && kv.second.ptr && hipFree(kv.second.ptr) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(%s) failed", kv.first.c_str());
     if (ctx->tb_scratch && hipFree(ctx->tb_scratch) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(scratch) failed");
     if (ctx->saved_sum && hipFree(ctx->saved_sum) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(saved) failed");
+    for (int i = 0; i < 2; i++)
+        if (ctx->shell_strip[i] && hipFree(ctx->shell_strip[i]) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(shell strip) failed");
     fdtdx_comm_release(ctx);
     for (auto &kv : ctx->addr)
         if (kv.second.ptr && hipFree(kv.second.ptr) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(%s) failed", kv.first.c_str());
@@ -407,7 +415,7 @@ static void default_shape(int kind, int r, int nq, int *tq, int *ly, int *ry)
     switch (r) {
     case 5: *tq = 64, *ly = 16, *ry = 1; break;
     case 6: *tq = 64, *ly = 16, *ry = 1; break;
-    case 7: *tq = 32, *ly = 16, *ry = 1; break;
+    case 7: *tq = 32, *ly = 32, *ry = 1; break;  // level with 32 x 16 in a lone sweep, 6 % ahead of it in a time loop (shell strips)
     default: *tq = 32, *ly = 32, *ry = 1; break;
     }
 }
@@ -415,7 +423,7 @@ static void default_shape(int kind, int r, int nq, int *tq, int *ly, int *ry)
 // [z2_lo, z2_hi): a second plane range swept by the same launch (empty: none)
 static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx_program *prog, uint64_t z_lo, uint64_t z_hi, void *stream,
                         const fdtdx_composite *comp = nullptr, const float *vel = nullptr, float *sum = nullptr, const int64_t *sel = nullptr,
-                        uint64_t z2_lo = 0, uint64_t z2_hi = 0)
+                        uint64_t z2_lo = 0, uint64_t z2_hi = 0, const float *shell = nullptr)
 {
     int r;
     int rc;
@@ -454,6 +462,7 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
     memset(p.c, 0, sizeof(p.c));
     memcpy(p.c, prog->coef, 13 * sizeof(float));
     p.vel = vel;
+    p.shell = shell, p.shell_plane = (long long)ctx->cfg.Y * 8;
     p.zg0 = (int)g.first_global;
     memset(p.kd, 0, sizeof(p.kd));
     p.sum = sum;
@@ -749,6 +758,35 @@ extern "C" int fdtdx_propagate2_planes(fdtdx_ctx *ctx, const char *out, const ch
     return fdtdx_propagate_fused_planes(ctx, out, in, mid, prog, 2, z_lo, z_hi, stream);
 }
 
+// The quads of a row that straddle the x shell (at most one on each side: quads ql and qr, -1: none), copied into a strip of
+// two quads per row: what a time loop's single-step sweeps merge into those quads instead of re-reading them from the
+// output cube every step (64-byte sectors for 16 bytes: 65 MB per 512^3 sweep, 6 % of its time at radius 7).
+__global__ void gather_shell_kernel(const float *cube, float *strip, long long plane, int px, int ny, long long rows, int ql, int qr)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * rows) return;
+    const long long row = i >> 1;
+    const int q = (i & 1) ? qr : ql;
+    const long long z = row / ny, y = row % ny;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q >= 0) v = *reinterpret_cast<const float4 *>(cube + z * plane + y * px + 4 * q);
+    reinterpret_cast<float4 *>(strip)[i] = v;
+}
+
+// fills ctx->shell_strip[i] from cube[i] for a program of radius r; false: no strips (not allocated, or no such quads)
+static bool gather_shell(fdtdx_ctx *ctx, float *const (&cube)[2], int r, void *stream)
+{
+    const int nx = (int)ctx->cfg.X;
+    const int ql = (r % 4 != 0) ? r / 4 : -1, qr = ((nx - r) % 4 != 0) ? (nx - r) / 4 : -1;
+    if (!ctx->shell_strip[0] || !ctx->shell_strip[1] || (ql < 0 && qr < 0) || nx < 2 * r + 1) return false;
+    const long long rows = (long long)ctx->g.local_planes * (long long)ctx->cfg.Y;
+    if (2 * rows > 0x7fffffffLL * 256) return false;
+    for (int i = 0; i < 2; i++)
+        hipLaunchKernelGGL(gather_shell_kernel, dim3((unsigned)((2 * rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cube[i], ctx->shell_strip[i],
+                           (long long)ctx->g.plane, (int)ctx->g.pitch_x, (int)ctx->cfg.Y, rows, ql, qr);
+    return hipGetLastError() == hipSuccess;
+}
+
 // `work`: a third cube for the two-step loops that need one (nullptr: allocated on first use and kept by the context)
 static int sweep_loop(fdtdx_ctx *ctx, const char *a, const char *b, const char *work, bool may_allocate, const fdtdx_program *prog,
                       uint32_t steps, void *stream)
@@ -843,11 +881,14 @@ static int sweep_loop(fdtdx_ctx *ctx, const char *a, const char *b, const char *
             }
         }
     }
-    // remaining single steps: level `done` is in b if done is even, in a if odd
+    // remaining single steps: level `done` is in b if done is even, in a if odd.  Where there are more than a few, the
+    // star sweeps take the shell components of partly stored quads from strips gathered once, here.
+    float *const both[2] = {pa, pb};
+    const bool strips = prog->kind != FDTDX_SPC13 && steps - done >= 8 && gather_shell(ctx, both, r, stream);
     for (uint32_t t = done; t < steps; t++) {
         float *out = (t % 2 == 0) ? pa : pb;
         const float *in = (t % 2 == 0) ? pb : pa;
-        rc = launch_sweep(ctx, out, in, prog, lo, hi, stream);
+        rc = launch_sweep(ctx, out, in, prog, lo, hi, stream, nullptr, nullptr, nullptr, nullptr, 0, 0, strips ? ctx->shell_strip[t % 2] : nullptr);
         if (rc) return rc;
     }
     return FDTDX_OK;

@@ -43,6 +43,7 @@ struct fdtdx_ctx {
     int64_t opt_boundary_stream = 0;   // 1: a multi-rank step's boundary-plane sweep runs on a stream of its own, beside the interior sweep
     int64_t opt_reserve_cus = 0;       // CUs a sweep launch leaves without a workgroup (room for the exchange's kernels)
     float *tb_scratch = nullptr;       // third cube of the fused time loop (owned)
+    float *shell_strip[2] = {nullptr, nullptr};  // time loops: the shell components of the quads that straddle the x shell, per cube of the loop (owned)
     float *saved_sum = nullptr;        // fdtdx_composite_step: sum values at the injection addresses
     size_t saved_cap = 0;
     float *static_scratch = nullptr;   // device address of the file-scope `scratch` array on ctx->device

@@ -94,7 +94,8 @@ struct Comp {
 template <int M, int TQ, int LY, int RY, int ORDER, int PF, int PH>
 __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], float4 (&eo)[RY],
                                            float4 (&hv)[star_nhk(M, TQ, LY, RY)], const Lane<RY, star_nhk(M, TQ, LY, RY)> &L,
-                                           float4 *buf, const float *&pn, const float *&pc, float *&po, bool more_n, bool more_c,
+                                           float4 *buf, const float *&pn, const float *&pc, float *&po, const float *&pe, long long ep,
+                                           bool more_n, bool more_c,
                                            unsigned plane_bytes, const float (&c)[7], Comp<RY> &cs, int gz)
 {
     constexpr int HQ = (M + 3) / 4;
@@ -115,7 +116,8 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
     const long long pf = plane_bytes >> 2;
     const __amdgpu_buffer_rsrc_t rn = make_rsrc(pn, nbn);        // plane z+M+PF
     const __amdgpu_buffer_rsrc_t rc = make_rsrc(pc + pf, nbc);   // halo of plane z+1
-    const __amdgpu_buffer_rsrc_t ron = make_rsrc(po + pf, nbc);  // shell components of output plane z+1
+    // shell components of output plane z+1: from the output cube, or from the strip kept beside it
+    const __amdgpu_buffer_rsrc_t ron = pe ? make_rsrc(pe + ep, more_c ? (unsigned)(ep * 4) : 0u) : make_rsrc(po + pf, nbc);
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(po, plane_bytes);
     float4 eo_cur[RY], vq_cur[RY], sq_cur[RY];
     const bool fuse_mul = is_composite(ORDER) && cs.ps != nullptr;  // uniform
@@ -269,6 +271,7 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
     pn += pf;
     pc += pf;
     po += pf;
+    if (pe) pe += ep;
     if constexpr (is_composite(ORDER)) {
         cs.pv += pf;
         if (fuse_mul) cs.ps += pf;
@@ -325,6 +328,8 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
         L.soff[j] = cok ? off : OOB;
         // the composite update reads the old output of every cell it computes, not only the shell components
         L.eoff[j] = (cok && (!mall || is_composite(ORDER))) ? off : OOB;
+        if (!is_composite(ORDER) && p.shell)  // strip entry (row, side): the left such quad of a row is the one whose first cell is shell
+            L.eoff[j] = (cok && !mall) ? (unsigned)(2 * y + (L.m0 ? 1 : 0)) * 16u : OOB;
         L.lown[j] = (M + ty + j * LY) * LPQ + HQ + tx;
         L.yrow[j] = y;
     }
@@ -370,8 +375,11 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
     float *po = p.out + (long long)zs * p.plane;
 #pragma unroll
     for (int k = 0; k < NHK; k++) hv[k] = buf_ld4(make_rsrc(pc, plane_bytes), L.hgoff[k]);
+    const bool strip = !is_composite(ORDER) && p.shell != nullptr;  // uniform
+    const long long ep = strip ? p.shell_plane : 0;
+    const float *pe = strip ? p.shell + (long long)zs * ep : nullptr;
 #pragma unroll
-    for (int j = 0; j < RY; j++) eo[j] = buf_ld4(make_rsrc(po, plane_bytes), L.eoff[j]);
+    for (int j = 0; j < RY; j++) eo[j] = buf_ld4(strip ? make_rsrc(pe, (unsigned)(ep * 4)) : make_rsrc(po, plane_bytes), L.eoff[j]);
     const float *pn = pc + (long long)(M + PF) * p.plane;  // plane z+M+PF, loaded while plane z is computed
     const int zn_end = min(ze, zlast - (M + PF));          // first z whose plane z+M+PF is not needed/not there
 
@@ -400,7 +408,7 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
     while (z < ze) {
         unroll_phases<0, QT>([&](auto ph) {
             if (z < ze) {
-                plane_step<M, TQ, LY, RY, ORDER, PF, decltype(ph)::value>(q, eo, hv, L, lds[par], pn, pc, po, z < zn_end, z + 1 < ze,
+                plane_step<M, TQ, LY, RY, ORDER, PF, decltype(ph)::value>(q, eo, hv, L, lds[par], pn, pc, po, pe, ep, z < zn_end, z + 1 < ze,
                                                                         plane_bytes, c, cs, p.zg0 + z);
                 par ^= 1;
                 z++;

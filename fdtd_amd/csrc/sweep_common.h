@@ -32,6 +32,11 @@ struct SweepParams {
     int gx, gy, gz;   // logical grid of tiles: x tiles, y tiles, z chunks (launched as gx*gy*gz blocks in 1-D)
     int gz1, z_lo2, z_hi2;  // z chunks gz1 .. gz-1 belong to a second plane range [z_lo2, z_hi2) (gz1 == gz: there is none)
     float c[13];
+    // Shell components of the quads that straddle the x shell, kept beside the output cube for the time loops: a strip of
+    // two quads per row (the row's left and right such quad) and `shell_plane` floats per plane, holding what the output
+    // cube holds there (its shell never changes).  nullptr: they are read from the output cube itself.
+    const float *shell;
+    long long shell_plane;
     // composite update only (main.cu): second input cube, global z of local plane 0, and the
     // constants {cz, cy, cx, snum, sden, wx, wy, wz} as doubles
     const float *vel;
