@@ -176,7 +176,10 @@ int fdtdx_propagate2_planes(fdtdx_ctx *ctx, const char *out, const char *in, con
 /* The drivers' time loop on one rank (fdtd1.cu:68-80 with nprocs == 1): `steps` ping-pong
  * steps, step 0 writes a = f(b), then the roles swap.  On return cube `a`/`b` hold exactly what
  * the reference's two cubes hold after the same number of steps.
- * Memory: the fused loops of the radius-1 programs (three steps per launch) and of the 13-point program (two steps per
+ * Memory: every context holds two strips of 8 floats per row of its local cube (0.4 % of a cube each, allocated by
+ * fdtdx_create; the loops do without them if that allocation failed), into which the loops gather, once per call, the
+ * shell cells of the quads that straddle the x shell, so that the sweeps need not re-read them from the output cube.
+ * The fused loops of the radius-1 programs (three steps per launch) and of the 13-point program (two steps per
  * launch, in place) run between the two cubes alone.  The two-step loop of the radius-2 star (and of the radius-1
  * programs under option "temporal" = 2) hops between b and a THIRD cube of the same size that carries b's shell.
  * fdtdx_sweep allocates that cube on the first such call (hipMalloc, +50 % footprint, kept until fdtdx_destroy) and runs
