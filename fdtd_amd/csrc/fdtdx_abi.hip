@@ -520,7 +520,9 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
         chunks = std::max<long long>(1, cus / tiles);  // never more workgroups than CUs: a second round would run nearly empty
         if (threads <= 256) chunks *= 2;  // small workgroups: two per CU
         const long long min_len = std::max<long long>(12LL * r, 16);
-        chunks = std::min(chunks, std::max<long long>(1, nz / min_len));
+        // (a handful of planes -- the boundary planes of a slab -- are the exception: such a launch is all start-up latency,
+        // and two chunks halve the planes a workgroup marches: 15.5 -> 11.3 us for 8 planes at radius 8)
+        chunks = std::min(chunks, nz < min_len && nz >= 2 ? 2LL : std::max<long long>(1, nz / min_len));
     }
     chunks = std::max<long long>(1, std::min(chunks, nz));
     p.zchunk = (int)((nz + chunks - 1) / chunks);
