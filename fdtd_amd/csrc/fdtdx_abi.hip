@@ -462,6 +462,9 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
     memset(p.c, 0, sizeof(p.c));
     memcpy(p.c, prog->coef, 13 * sizeof(float));
     p.vel = vel;
+    if (!shell && !comp && ctx->strip_radius == r)
+        for (int i = 0; i < 2; i++)
+            if (ctx->strip_cube[i] == out) shell = ctx->shell_strip[i];
     p.shell = shell, p.shell_plane = (long long)ctx->cfg.Y * 8;
     p.zg0 = (int)g.first_global;
     memset(p.kd, 0, sizeof(p.kd));
@@ -776,8 +779,11 @@ __global__ void gather_shell_kernel(const float *cube, float *strip, long long p
 }
 
 // fills ctx->shell_strip[i] from cube[i] for a program of radius r; false: no strips (not allocated, or no such quads)
-static bool gather_shell(fdtdx_ctx *ctx, float *const (&cube)[2], int r, void *stream)
+bool fdtdx_strips_bind(fdtdx_ctx *ctx, const float *a, const float *b, int r, void *stream)
 {
+    const float *cube[2] = {a, b};
+    ctx->strip_radius = 0;
+    if (hipSetDevice(ctx->device) != hipSuccess) return false;
     const int nx = (int)ctx->cfg.X;
     const int ql = (r % 4 != 0) ? r / 4 : -1, qr = ((nx - r) % 4 != 0) ? (nx - r) / 4 : -1;
     if (!ctx->shell_strip[0] || !ctx->shell_strip[1] || (ql < 0 && qr < 0) || nx < 2 * r + 1) return false;
@@ -786,8 +792,11 @@ static bool gather_shell(fdtdx_ctx *ctx, float *const (&cube)[2], int r, void *s
     for (int i = 0; i < 2; i++)
         hipLaunchKernelGGL(gather_shell_kernel, dim3((unsigned)((2 * rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cube[i], ctx->shell_strip[i],
                            (long long)ctx->g.plane, (int)ctx->g.pitch_x, (int)ctx->cfg.Y, rows, ql, qr);
-    return hipGetLastError() == hipSuccess;
+    if (hipGetLastError() != hipSuccess) return false;
+    ctx->strip_cube[0] = a, ctx->strip_cube[1] = b, ctx->strip_radius = r;
+    return true;
 }
+void fdtdx_strips_release(fdtdx_ctx *ctx) { ctx->strip_radius = 0; }
 
 // `work`: a third cube for the two-step loops that need one (nullptr: allocated on first use and kept by the context)
 static int sweep_loop(fdtdx_ctx *ctx, const char *a, const char *b, const char *work, bool may_allocate, const fdtdx_program *prog,
@@ -885,15 +894,14 @@ static int sweep_loop(fdtdx_ctx *ctx, const char *a, const char *b, const char *
     }
     // remaining single steps: level `done` is in b if done is even, in a if odd.  Where there are more than a few, the
     // star sweeps take the shell components of partly stored quads from strips gathered once, here.
-    float *const both[2] = {pa, pb};
-    const bool strips = prog->kind != FDTDX_SPC13 && steps - done >= 8 && gather_shell(ctx, both, r, stream);
-    for (uint32_t t = done; t < steps; t++) {
+    if (prog->kind != FDTDX_SPC13 && steps - done >= 8) (void)fdtdx_strips_bind(ctx, pa, pb, r, stream);
+    for (uint32_t t = done; t < steps && !rc; t++) {
         float *out = (t % 2 == 0) ? pa : pb;
         const float *in = (t % 2 == 0) ? pb : pa;
-        rc = launch_sweep(ctx, out, in, prog, lo, hi, stream, nullptr, nullptr, nullptr, nullptr, 0, 0, strips ? ctx->shell_strip[t % 2] : nullptr);
-        if (rc) return rc;
+        rc = launch_sweep(ctx, out, in, prog, lo, hi, stream);
     }
-    return FDTDX_OK;
+    fdtdx_strips_release(ctx);
+    return rc;
 }
 
 extern "C" int fdtdx_sweep(fdtdx_ctx *ctx, const char *a, const char *b, const fdtdx_program *prog, uint32_t steps, void *stream)

@@ -512,10 +512,20 @@ extern "C" int fdtdx_run(fdtdx_ctx *const *ctxs, int n, const char *a, const cha
             done += 2;
         }
     }
-    for (uint32_t t = done; t < steps; t++) {
+    // single steps: where there are more than a few, the sweeps take the shell components of partly stored quads from strips
+    // gathered once, here (the cubes' shells do not change while the loop runs)
+    if (prog->kind != FDTDX_SPC13 && steps - done >= 8)
+        for (int i = 0; i < n; i++) {
+            float *pa, *pb;
+            if (fdtdx_find_cube(ctxs[i], a, &pa) == FDTDX_OK && fdtdx_find_cube(ctxs[i], b, &pb) == FDTDX_OK)
+                (void)fdtdx_strips_bind(ctxs[i], pa, pb, (int)r, stream_of(i));
+        }
+    rc = FDTDX_OK;
+    for (uint32_t t = done; t < steps && !rc; t++) {
         const char *out = (t % 2 == 0) ? a : b, *in = (t % 2 == 0) ? b : a;
-        if ((rc = each([&](int i) { return fdtdx_step_begin(ctxs[i], out, in, prog, stream_of(i)); }))) return rc;
-        if ((rc = each([&](int i) { return fdtdx_step_end(ctxs[i], stream_of(i)); }))) return rc;
+        rc = each([&](int i) { return fdtdx_step_begin(ctxs[i], out, in, prog, stream_of(i)); });
+        if (!rc) rc = each([&](int i) { return fdtdx_step_end(ctxs[i], stream_of(i)); });
     }
-    return FDTDX_OK;
+    for (int i = 0; i < n; i++) fdtdx_strips_release(ctxs[i]);
+    return rc;
 }

@@ -44,6 +44,8 @@ struct fdtdx_ctx {
     int64_t opt_reserve_cus = 0;       // CUs a sweep launch leaves without a workgroup (room for the exchange's kernels)
     float *tb_scratch = nullptr;       // third cube of the fused time loop (owned)
     float *shell_strip[2] = {nullptr, nullptr};  // time loops: the shell components of the quads that straddle the x shell, per cube of the loop (owned)
+    const float *strip_cube[2] = {nullptr, nullptr};  // the cubes the strips mirror while a time loop runs
+    int strip_radius = 0;                             // radius they were gathered for (0: the strips are not valid)
     float *saved_sum = nullptr;        // fdtdx_composite_step: sum values at the injection addresses
     size_t saved_cap = 0;
     float *static_scratch = nullptr;   // device address of the file-scope `scratch` array on ctx->device
@@ -64,6 +66,10 @@ struct fdtdx_ctx {
 
 int fdtdx_find_cube(fdtdx_ctx *ctx, const char *name, float **p);
 // is there a fused kernel of kt steps per launch for the program on this context's grid (shells: one that takes both shell sources by name)?
+// Time loops: gather the strips for cubes a and b (a program of radius r) on `stream` / forget them.  While bound, single-step
+// star sweeps into a or b take the shell components of partly stored quads from the strips.
+bool fdtdx_strips_bind(fdtdx_ctx *ctx, const float *a, const float *b, int r, void *stream);
+void fdtdx_strips_release(fdtdx_ctx *ctx);
 bool fdtdx_has_fused(const fdtdx_ctx *ctx, const fdtdx_program *prog, int kt, bool shells);
 // one launch over two plane ranges, the second behind the first (either may be empty)
 int fdtdx_propagate_two_ranges(fdtdx_ctx *ctx, const char *out, const char *in, const fdtdx_program *prog, uint64_t z_lo, uint64_t z_hi,
