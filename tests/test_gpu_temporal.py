@@ -213,3 +213,19 @@ def test_sweep_work_takes_the_third_cube_by_name(oracle_cpu, steps, work):
             st.sweep("p0", "p1", make_program("star", radius=M), steps, work="p1")
     assert ("fused2" in info) == (work is not None), info
     assert np.array_equal(ga.view(np.uint32), ca.view(np.uint32)) and np.array_equal(gb.view(np.uint32), cb.view(np.uint32)), info
+
+
+@pytest.mark.parametrize("golden", [False, True], ids=["device-order", "golden-order"])
+@pytest.mark.parametrize("X", [61, 64, 130, 509, 515])
+@pytest.mark.parametrize("M", [1, 2, 3, 5, 6, 7])
+def test_single_step_loops_take_shell_cells_from_the_strips(oracle_cpu, M, X, golden):
+    """Loops of eight and more single steps gather the shell cells of the quads that straddle the x shell into strips once
+    and merge them from there (instead of re-reading the output cube every step): every radius that is not a multiple of
+    4, row lengths that put one, two or three interior cells into the last such quad, both orders."""
+    info = run(oracle_cpu, "star", (2 * M + 9, 2 * M + 23, X), 9, temporal=0, M=M, golden=golden)
+    assert "fused" not in info
+
+
+def test_single_step_jacobi_loop_with_strips(oracle_cpu):
+    run(oracle_cpu, "jacobi7", (11, 25, 130), 10, temporal=0)
+
