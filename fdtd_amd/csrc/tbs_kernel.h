@@ -238,8 +238,11 @@ __global__ __launch_bounds__(NW * 64) void tb_spc_kernel(const TbParams p)
             const __amdgpu_buffer_rsrc_t rm = rsrc_of(p.mid, more ? pz - 1 : -1);
 #pragma unroll
             for (int j = 0; j < RY; j++) {
+                // a row (or plane) that is shell throughout is read from `even` in the first place: a choice between two
+                // descriptors, uniform over the wave, instead of a second load later
+                const bool whole = more && patch && (zshell(pz + 1) || ((yfull >> j) & 1u));
 #pragma unroll
-                for (int i = 0; i < RX; i++) nx[j][i] = buf_ld4(rn, goff[j][i]);
+                for (int i = 0; i < RX; i++) nx[j][i] = buf_ld4(whole ? re : rn, goff[j][i]);
                 mvx[j] = buf_ld4(rm, shq[j]);
                 evx[j] = buf_ld4(re, shq[j]);
             }
@@ -307,7 +310,12 @@ __global__ __launch_bounds__(NW * 64) void tb_spc_kernel(const TbParams p)
         for (int j = 0; j < RY; j++)
 #pragma unroll
             for (int i = 0; i < RX; i++) q0[OLD][j][i] = nx[j][i];
-        if (patch) merge_shell(q0[OLD], evx, p.even, pz + 1);
+        if (patch && !zshell(pz + 1)) {  // the x shell cells of the rows that are not shell throughout
+#pragma unroll
+            for (int j = 0; j < RY; j++)
+#pragma unroll
+                for (int i = 0; i < RX; i++) q0[OLD][j][i] = select4(((yfull >> j) & 1u) ? 0xFu : flags[j][i], q0[OLD][j][i], evx[j]);
+        }
         pz++;
     };
 
