@@ -126,9 +126,26 @@ def spawn_ranks(n):
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0 = procs[0].communicate()[0]
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0)
+    # a rank that dies (no such GPU, a failed launch) must not leave the others waiting at a rendezvous: watch them all,
+    # and end the rest (the children this function started, by their own handles) when one fails
+    import threading
+    box = []
+    reader = threading.Thread(target=lambda: box.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(c is not None for c in rcs):
+            break
+        if any(c not in (None, 0) for c in rcs):
+            time.sleep(5.0)  # let the failing rank's message out, then stop the ranks still running
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            rcs = [p.wait() for p in procs]
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10.0)
+    sys.stdout.write(box[0] if box else "")
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
     if bad:
