@@ -731,7 +731,7 @@ static int fused_launch_checked(fdtdx_ctx *ctx, const char *out, const char *in,
 }
 
 // One launch over two plane ranges (the planes next to either neighbour of a slab): for the multi-slab step.
-int fdtdx_propagate_two_ranges(fdtdx_ctx *ctx, const char *out, const char *in, const fdtdx_program *prog, uint64_t z_lo, uint64_t z_hi,
+extern "C" int fdtdx_propagate_two_ranges(fdtdx_ctx *ctx, const char *out, const char *in, const fdtdx_program *prog, uint64_t z_lo, uint64_t z_hi,
                                uint64_t z2_lo, uint64_t z2_hi, void *stream)
 {
     float *po, *pi;
@@ -739,7 +739,7 @@ int fdtdx_propagate_two_ranges(fdtdx_ctx *ctx, const char *out, const char *in, 
     if ((rc = fdtdx_find_cube(ctx, out, &po)) || (rc = fdtdx_find_cube(ctx, in, &pi))) return rc;
     return launch_sweep(ctx, po, pi, prog, z_lo, z_hi, stream, nullptr, nullptr, nullptr, nullptr, z2_lo, z2_hi);
 }
-int fdtdx_propagate_fused_two_ranges(fdtdx_ctx *ctx, const char *out, const char *in, const char *even, const char *odd, const fdtdx_program *prog,
+extern "C" int fdtdx_propagate_fused_two_ranges(fdtdx_ctx *ctx, const char *out, const char *in, const char *even, const char *odd, const fdtdx_program *prog,
                                      uint32_t nsteps, uint64_t z_lo, uint64_t z_hi, uint64_t z2_lo, uint64_t z2_hi, void *stream)
 {
     return fused_launch_checked(ctx, out, in, even, odd, prog, nsteps, z_lo, z_hi, stream, z2_lo, z2_hi);

@@ -71,9 +71,4 @@ int fdtdx_find_cube(fdtdx_ctx *ctx, const char *name, float **p);
 bool fdtdx_strips_bind(fdtdx_ctx *ctx, const float *a, const float *b, int r, void *stream);
 void fdtdx_strips_release(fdtdx_ctx *ctx);
 bool fdtdx_has_fused(const fdtdx_ctx *ctx, const fdtdx_program *prog, int kt, bool shells);
-// one launch over two plane ranges, the second behind the first (either may be empty)
-int fdtdx_propagate_two_ranges(fdtdx_ctx *ctx, const char *out, const char *in, const fdtdx_program *prog, uint64_t z_lo, uint64_t z_hi,
-                               uint64_t z2_lo, uint64_t z2_hi, void *stream);
-int fdtdx_propagate_fused_two_ranges(fdtdx_ctx *ctx, const char *out, const char *in, const char *even, const char *odd, const fdtdx_program *prog,
-                                     uint32_t nsteps, uint64_t z_lo, uint64_t z_hi, uint64_t z2_lo, uint64_t z2_hi, void *stream);
 void fdtdx_comm_release(fdtdx_ctx *ctx);  // called by fdtdx_destroy

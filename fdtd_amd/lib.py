@@ -81,6 +81,9 @@ SYMBOLS = {
     "fdtdx_propagate_fused_shells": (ctypes.c_int, [_vp, _c, _c, _c, _c, _P(Program), ctypes.c_uint32, ctypes.c_uint64,
                                                     ctypes.c_uint64, _vp]),
     "fdtdx_propagate2_planes": (ctypes.c_int, [_vp, _c, _c, _c, _P(Program), ctypes.c_uint64, ctypes.c_uint64, _vp]),
+    "fdtdx_propagate_two_ranges": (ctypes.c_int, [_vp, _c, _c, _P(Program), ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, _vp]),
+    "fdtdx_propagate_fused_two_ranges": (ctypes.c_int, [_vp, _c, _c, _c, _c, _P(Program), ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64,
+                                                        ctypes.c_uint64, ctypes.c_uint64, _vp]),
     "fdtdx_sweep": (ctypes.c_int, [_vp, _c, _c, _P(Program), ctypes.c_uint32, _vp]),
     "fdtdx_sweep_work": (ctypes.c_int, [_vp, _c, _c, _c, _P(Program), ctypes.c_uint32, _vp]),
     "fdtdx_propagate_composite_planes": (ctypes.c_int, [_vp, _c, _c, _c, _P(Composite), ctypes.c_uint64, ctypes.c_uint64, _vp]),

@@ -131,6 +131,16 @@ class Stencil:
                                                         shell_odd.encode(), ctypes.byref(program), nsteps, z_lo, z_hi,
                                                         ctypes.c_void_p(stream or 0)))
 
+    def propagateTwoRanges(self, out, inp, program, z_lo, z_hi, z2_lo, z2_hi, stream=None):
+        """propagateHaloTopBackup + propagateHaloButtomBackup (stencil.h:770-808) as one launch over two plane ranges."""
+        _lib.check(self._L.fdtdx_propagate_two_ranges(self._h, out.encode(), inp.encode(), ctypes.byref(program), z_lo, z_hi, z2_lo, z2_hi,
+                                                      ctypes.c_void_p(stream or 0)))
+
+    def propagateFusedTwoRanges(self, out, inp, shell_even, shell_odd, program, nsteps, z_lo, z_hi, z2_lo, z2_hi, stream=None):
+        _lib.check(self._L.fdtdx_propagate_fused_two_ranges(self._h, out.encode(), inp.encode(), shell_even.encode(), shell_odd.encode(),
+                                                            ctypes.byref(program), nsteps, z_lo, z_hi, z2_lo, z2_hi,
+                                                            ctypes.c_void_p(stream or 0)))
+
     def sweep(self, a, b, program, steps, stream=None, work=False):
         """The drivers' whole time loop on one rank (fdtd1.cu:68-80).  work=False: the library allocates the third cube
         the radius-2 two-step loop hops through on first use; work="name": that cube of the pool is used; work=None:

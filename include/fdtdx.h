@@ -140,6 +140,11 @@ int fdtdx_propagate(fdtdx_ctx *ctx, const char *out, const char *in, const fdtdx
  * split that replaces propagateHalo{Top,Buttom}Backup (stencil.h:770-808). */
 int fdtdx_propagate_planes(fdtdx_ctx *ctx, const char *out, const char *in, const fdtdx_program *prog,
                            uint64_t z_lo, uint64_t z_hi, void *stream);
+/* propagateHaloTopBackup and propagateHaloButtomBackup (stencil.h:770-808) as ONE launch: two plane ranges, the second
+ * behind the first (either may be empty).  Two launches of a handful of planes in a row each leave most of the device
+ * idle; fdtdx_step_begin sweeps the planes next to both neighbours this way. */
+int fdtdx_propagate_two_ranges(fdtdx_ctx *ctx, const char *out, const char *in, const fdtdx_program *prog,
+                               uint64_t z_lo, uint64_t z_hi, uint64_t z2_lo, uint64_t z2_hi, void *stream);
 /* Raw-pointer form for callers that manage their own cubes (same layout/geometry as ctx). */
 int fdtdx_propagate_ptr(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx_program *prog,
                         uint64_t z_lo, uint64_t z_hi, void *stream);
@@ -169,6 +174,10 @@ int fdtdx_propagate_fused_planes(fdtdx_ctx *ctx, const char *out, const char *in
 int fdtdx_propagate_fused_shells(fdtdx_ctx *ctx, const char *out, const char *in, const char *shell_even,
                                  const char *shell_odd, const fdtdx_program *prog, uint32_t nsteps, uint64_t z_lo,
                                  uint64_t z_hi, void *stream);
+/* ... over two plane ranges in one launch (see fdtdx_propagate_two_ranges; fdtdx_hop_begin uses it). */
+int fdtdx_propagate_fused_two_ranges(fdtdx_ctx *ctx, const char *out, const char *in, const char *shell_even,
+                                     const char *shell_odd, const fdtdx_program *prog, uint32_t nsteps, uint64_t z_lo,
+                                     uint64_t z_hi, uint64_t z2_lo, uint64_t z2_hi, void *stream);
 /* nsteps = 2 */
 int fdtdx_propagate2_planes(fdtdx_ctx *ctx, const char *out, const char *in, const char *mid,
                             const fdtdx_program *prog, uint64_t z_lo, uint64_t z_hi, void *stream);

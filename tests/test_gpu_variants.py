@@ -116,3 +116,29 @@ def test_error_codes_instead_of_asserts():
         st.free("p1")
         with pytest.raises(FdtdxError):
             st.free("p1")
+
+
+@pytest.mark.parametrize("kind,M", [("star", 1), ("star", 3), ("star", 8), ("spc13", 1), ("jacobi7", 1)])
+def test_two_plane_ranges_in_one_launch(kind, M):
+    """fdtdx_propagate_two_ranges: the planes next to either neighbour of a slab swept by ONE launch equal two launches
+    bit for bit; either range may be empty; a second range in front of the first is refused."""
+    Z, Y, X = 40, 37, 150
+    prog = make_program(kind, radius=M)
+    with Stencil(Z, Y, X, M) as st:
+        for name in ("in", "one", "two"):
+            st.mallocCube(name)
+        st.initMt("in", "one")
+        st.initMt("in", "two")
+        lo, hi = M, Z - M
+        for (a0, a1, b0, b1) in ((lo, lo + 3, hi - 5, hi), (lo, lo, hi - 2, hi), (lo + 1, lo + 4, hi, hi), (lo, lo + 7, lo + 7, lo + 9)):
+            st.propagateTwoRanges("one", "in", prog, a0, a1, b0, b1)
+            st.propagatePlanes("two", "in", prog, a0, a1)
+            st.propagatePlanes("two", "in", prog, b0, b1)
+            st.sync()
+            one, two = np.empty((Z, Y, X), np.float32), np.empty((Z, Y, X), np.float32)
+            st.transferCubeToCPU(one, "one")
+            st.transferCubeToCPU(two, "two")
+            assert np.array_equal(one.view(np.uint32), two.view(np.uint32)), (a0, a1, b0, b1)
+        with pytest.raises(Exception):
+            st.propagateTwoRanges("one", "in", prog, lo + 5, lo + 8, lo, lo + 2)
+
