@@ -58,9 +58,34 @@ __device__ __forceinline__ f32x2 pair_or_chain2(f32x2 acc, float cp, f32x2 vp, f
     }
 }
 
+constexpr int star_nhq(int M, int TQ, int LY, int RY)  // halo quads of a tile: M rows above and below, ceil(M/4) quads left and right
+{
+    return 2 * M * TQ + LY * RY * 2 * ((M + 3) / 4);
+}
 constexpr int star_nhk(int M, int TQ, int LY, int RY)
 {
     return (2 * M * TQ + LY * RY * 2 * ((M + 3) / 4) + TQ * LY - 1) / (TQ * LY);
+}
+
+// Halo ring: a tile's halo quads of plane P are the own quads of the neighbouring tiles, which fetch plane P as their
+// queue's newest plane M+PF-1 steps before P becomes the centre plane.  Fetched then, the halo finds the lines in the L2
+// the neighbours share (fetched when P is the centre plane, they have long been evicted: at radius 8 the halo costs as
+// much fabric traffic as if no tile shared anything).  Each thread parks its halo quads in an LDS ring of M+PF-1 planes
+// until their plane comes up; the ring entries are private to the thread, so no barrier is involved.
+#ifndef FDTDX_RING_MIN_M
+#define FDTDX_RING_MIN_M 3
+#endif
+// quads of a ring of `planes` planes: the halo quads of each plane, and one spare quad for every thread that has no halo
+// quad in its last round (it parks the zeros its masked load returns there, so that the ring traffic needs no branch)
+constexpr int star_ring_quads(int M, int TQ, int LY, int RY, int planes)
+{
+    return planes * star_nhq(M, TQ, LY, RY) + star_nhk(M, TQ, LY, RY) * TQ * LY - star_nhq(M, TQ, LY, RY);
+}
+constexpr int star_ring_planes(int M, int TQ, int LY, int RY, int ORDER, int PF)
+{
+    const int images = 2 * (LY * RY + 2 * M) * (TQ + 2 * ((M + 3) / 4)) * 16;
+    const int ring = star_ring_quads(M, TQ, LY, RY, M + PF - 1) * 16;
+    return (M >= FDTDX_RING_MIN_M && !is_composite(ORDER) && images + ring <= 160 * 1024) ? M + PF - 1 : 0;
 }
 
 // Per-thread constants of the march.
@@ -94,22 +119,38 @@ struct Comp {
 template <int M, int TQ, int LY, int RY, int ORDER, int PF, int PH>
 __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], float4 (&eo)[RY],
                                            float4 (&hv)[star_nhk(M, TQ, LY, RY)], const Lane<RY, star_nhk(M, TQ, LY, RY)> &L,
-                                           float4 *buf, const float *&pn, const float *&pc, float *&po, const float *&pe, long long ep,
-                                           bool more_n, bool more_c,
+                                           float4 *buf, float4 *ring, int &rslot, const float *&pn, const float *&pc, float *&po, const float *&pe,
+                                           long long ep, bool more_n, bool more_c,
                                            unsigned plane_bytes, const float (&c)[7], Comp<RY> &cs, int gz)
 {
     constexpr int HQ = (M + 3) / 4;
     constexpr int LPQ = TQ + 2 * HQ;
     constexpr int NHK = star_nhk(M, TQ, LY, RY);
     constexpr int QT = 2 * M + 1 + PF;
+    constexpr int RP = star_ring_planes(M, TQ, LY, RY, ORDER, PF);
+    constexpr int NT = TQ * LY;
+    constexpr int NHQ = star_nhq(M, TQ, LY, RY);
 #define QS(k) (((k) + PH) % QT)
 
     // publish the centre plane + halo
 #pragma unroll
     for (int j = 0; j < RY; j++) buf[L.lown[j]] = q[j][QS(M)];
+    if constexpr (RP > 0) {
+        // the halo of this plane leaves the ring; its slot takes the halo of plane z+M+PF-1, which the step before fetched
 #pragma unroll
-    for (int k = 0; k < NHK; k++)
-        if (L.hloff[k] >= 0) buf[L.hloff[k]] = hv[k];
+        for (int k = 0; k < NHK; k++) {
+            const int hidx = (int)threadIdx.x + k * NT;
+            float4 *rs = ring + ((k < NHK - 1 || hidx < NHQ) ? rslot * NHQ + hidx : RP * NHQ + hidx - NHQ);
+            const float4 h = *rs;
+            *rs = hv[k];
+            if (L.hloff[k] >= 0) buf[L.hloff[k]] = h;
+        }
+        rslot = (rslot + 1 == RP) ? 0 : rslot + 1;
+    } else {
+#pragma unroll
+        for (int k = 0; k < NHK; k++)
+            if (L.hloff[k] >= 0) buf[L.hloff[k]] = hv[k];
+    }
 
     // prefetches; where there is no such plane the descriptor is empty and the loads return 0
     const unsigned nbn = more_n ? plane_bytes : 0u, nbc = more_c ? plane_bytes : 0u;
@@ -138,7 +179,7 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
         }
     }
 #pragma unroll
-    for (int k = 0; k < NHK; k++) hv[k] = buf_ld4(rc, L.hgoff[k]);
+    for (int k = 0; k < NHK; k++) hv[k] = buf_ld4(RP > 0 ? rn : rc, L.hgoff[k]);
 #pragma unroll
     for (int j = 0; j < RY; j++)  // streamed past the caches where measured faster: full-row tiles (+2-4 % at radius 1 and 3; 3 % slower with x tiles)
         eo[j] = (is_composite(ORDER) || TQ >= 128) ? buf_ld4s(ron, L.eoff[j]) : buf_ld4(ron, L.eoff[j]);
@@ -294,7 +335,10 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
     static_assert(NHK == (NHQ + NT - 1) / NT, "halo count");
     constexpr int QT = 2 * M + 1 + PF;        // queue slots
 
+    constexpr int RP = star_ring_planes(M, TQ, LY, RY, ORDER, PF);  // planes of halo parked in LDS (0: none)
+
     __shared__ float4 lds[2][LROWS * LPQ];
+    __shared__ float4 ring[RP > 0 ? star_ring_quads(M, TQ, LY, RY, RP) : 1];
 
     const int t = threadIdx.x;
     const int tx = t % TQ, ty = t / TQ;
@@ -373,8 +417,23 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
     }
     const float *pc = p.in + (long long)zs * p.plane;  // centre plane
     float *po = p.out + (long long)zs * p.plane;
+    if constexpr (RP > 0) {
+        // ring slot i: halo of plane zs+i; the halo of plane zs+M+PF-1 is in flight like the one every step fetches
 #pragma unroll
-    for (int k = 0; k < NHK; k++) hv[k] = buf_ld4(make_rsrc(pc, plane_bytes), L.hgoff[k]);
+        for (int i = 0; i < RP; i++)
+#pragma unroll
+            for (int k = 0; k < NHK; k++) {
+                const int hidx = t + k * NT;
+                ring[(k < NHK - 1 || hidx < NHQ) ? i * NHQ + hidx : RP * NHQ + hidx - NHQ] =
+                    buf_ld4(make_rsrc(pc + (long long)i * p.plane, (zs + i < zlast) ? plane_bytes : 0u), L.hgoff[k]);
+            }
+#pragma unroll
+        for (int k = 0; k < NHK; k++)
+            hv[k] = buf_ld4(make_rsrc(pc + (long long)RP * p.plane, (zs + RP < zlast) ? plane_bytes : 0u), L.hgoff[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < NHK; k++) hv[k] = buf_ld4(make_rsrc(pc, plane_bytes), L.hgoff[k]);
+    }
     const bool strip = !is_composite(ORDER) && p.shell != nullptr;  // uniform
     const long long ep = strip ? p.shell_plane : 0;
     const float *pe = strip ? p.shell + (long long)zs * ep : nullptr;
@@ -405,12 +464,16 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
     // one copy of the plane body per queue slot: the queue advances by renaming, never by moves
     int z = zs;
     int par = 0;
+    int rslot = 0;
     while (z < ze) {
         unroll_phases<0, QT>([&](auto ph) {
             if (z < ze) {
-                plane_step<M, TQ, LY, RY, ORDER, PF, decltype(ph)::value>(q, eo, hv, L, lds[par], pn, pc, po, pe, ep, z < zn_end, z + 1 < ze,
+                plane_step<M, TQ, LY, RY, ORDER, PF, decltype(ph)::value>(q, eo, hv, L, lds[par], ring, rslot, pn, pc, po, pe, ep, z < zn_end, z + 1 < ze,
                                                                         plane_bytes, c, cs, p.zg0 + z);
                 par ^= 1;
+#ifdef FDTDX_DRIFT_PROBE
+                if (p.dbg && t == 0) p.dbg[blockIdx.x * 256 + (z - zs)] = wall_clock64();
+#endif
                 z++;
             }
         });
@@ -436,7 +499,7 @@ struct StarRegistrar {
         v.ry = RY;
         v.pf = PF;
         v.threads = TQ * LY;
-        v.lds_bytes = 2 * (LY * RY + 2 * M) * (TQ + 2 * HQ) * 16;
+        v.lds_bytes = 2 * (LY * RY + 2 * M) * (TQ + 2 * HQ) * 16 + (star_ring_planes(M, TQ, LY, RY, ORDER, PF) ? star_ring_quads(M, TQ, LY, RY, star_ring_planes(M, TQ, LY, RY, ORDER, PF)) * 16 : 0);
         v.launch = &star_launch<M, TQ, LY, RY, ORDER, PF>;
         register_variant(v);
     }

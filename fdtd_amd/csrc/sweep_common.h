@@ -44,6 +44,9 @@ struct SweepParams {
     double kd[8];
     float *sum;   // fused product-accumulate target (nullptr: none)
     int sel[3];   // global z, y, x of the planes filt scales afterwards (-1: none)
+#ifdef FDTDX_DRIFT_PROBE
+    unsigned long long *dbg;
+#endif
 };
 
 // Description of one compiled tile shape.
