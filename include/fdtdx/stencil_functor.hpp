@@ -107,6 +107,13 @@ __global__ __launch_bounds__(TXQ *LY) void functor_star_kernel(FunctorGeom g, T 
     constexpr int NHK = (NHQ + NT - 1) / NT;
     constexpr int QT = 2 * M + 2;                        // queue slots: planes z-M .. z+M and the load in flight
     __shared__ float4 lds[2][LROWS * LPQ];
+    // The tile's halo quads of plane P are own quads of the neighbouring tiles, which fetch plane P M steps before it is
+    // the centre plane; fetched then as well, the halo finds the lines in the L2 the tiles share (M steps later they
+    // are long evicted).  Each thread parks its halo quads in a ring of M planes until their plane comes up; a thread
+    // without a halo quad in its last round parks the zeros of its masked load in a spare quad, so nothing branches.
+    constexpr int RINGQ = M * NHQ + NHK * NT - NHQ;
+    constexpr int RP = (M >= 3 && (2 * LROWS * LPQ + RINGQ) * 16 <= 160 * 1024) ? M : 0;
+    __shared__ float4 ring[RP > 0 ? RINGQ : 1];
     // rows and planes are whole numbers of quads and cubes are 16-byte aligned (fdtdx_geometry): said out loud so
     // that the compiler may merge what the functor stores for the four cells of a quad
     __builtin_assume((g.px & 3) == 0);
@@ -179,10 +186,20 @@ __global__ __launch_bounds__(TXQ *LY) void functor_star_kernel(FunctorGeom g, T 
         for (int k = 0; k < QT - 1; k++) q[j][k] = plane_ld4(plane_of(zs - M + k), bytes_of(zs - M + k), goff[j]);
         q[j][QT - 1] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    auto ring_at = [&](int slot, int k) -> float4 & {
+        const int h = t + k * NT;
+        return ring[(k < NHK - 1 || h < NHQ) ? slot * NHQ + h : RP * NHQ + h - NHQ];
+    };
+    if constexpr (RP > 0) {
 #pragma unroll
-    for (int k = 0; k < NHK; k++) hv[k] = plane_ld4(plane_of(zs), plane_bytes, hgoff[k]);
+        for (int i = 0; i < RP; i++)
+#pragma unroll
+            for (int k = 0; k < NHK; k++) ring_at(i, k) = plane_ld4(plane_of(zs + i), bytes_of(zs + i), hgoff[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < NHK; k++) hv[k] = plane_ld4(plane_of(zs + RP), bytes_of(zs + RP), hgoff[k]);
 
-    int z = zs, par = 0;
+    int z = zs, par = 0, rslot = 0;
     while (z < ze) {
         phases<0, QT>([&](auto ph) {
             constexpr int PH = decltype(ph)::value;  // logical slot k (plane z-M+k) lives in physical slot (k+PH) % QT
@@ -190,16 +207,28 @@ __global__ __launch_bounds__(TXQ *LY) void functor_star_kernel(FunctorGeom g, T 
             float4 *buf = lds[par];
 #pragma unroll
             for (int j = 0; j < RY; j++) buf[lown[j]] = q[j][(M + PH) % QT];
+            if constexpr (RP > 0) {
+                // this plane's halo leaves the ring; its slot takes the halo of plane z+M, fetched by the step before
 #pragma unroll
-            for (int k = 0; k < NHK; k++)
-                if (hloff[k] >= 0) buf[hloff[k]] = hv[k];
-            // next plane: own quads of plane z+M+1 into the slot plane z-M-1 has left, halo of plane z+1
+                for (int k = 0; k < NHK; k++) {
+                    float4 &slot = ring_at(rslot, k);
+                    const float4 h = slot;
+                    slot = hv[k];
+                    if (hloff[k] >= 0) buf[hloff[k]] = h;
+                }
+                rslot = (rslot + 1 == RP) ? 0 : rslot + 1;
+            } else {
+#pragma unroll
+                for (int k = 0; k < NHK; k++)
+                    if (hloff[k] >= 0) buf[hloff[k]] = hv[k];
+            }
+            // next plane: own quads of plane z+M+1 into the slot plane z-M-1 has left, halo of plane z+1 (ring: z+M+1)
             const bool more = z + 1 < ze;
 #pragma unroll
             for (int j = 0; j < RY; j++)
                 q[j][(QT - 1 + PH) % QT] = plane_ld4(plane_of(z + M + 1), more ? bytes_of(z + M + 1) : 0u, goff[j]);
 #pragma unroll
-            for (int k = 0; k < NHK; k++) hv[k] = plane_ld4(plane_of(z + 1), more ? plane_bytes : 0u, hgoff[k]);
+            for (int k = 0; k < NHK; k++) hv[k] = plane_ld4(plane_of(z + 1 + RP), more ? bytes_of(z + 1 + RP) : 0u, hgoff[k]);
             __syncthreads();  // the other image is only rewritten after the next barrier, when everyone has left this plane's reads behind
 #pragma unroll
             for (int j = 0; j < RY; j++) {
