@@ -85,6 +85,9 @@ constexpr int star_ring_planes(int M, int TQ, int LY, int RY, int ORDER, int PF)
 {
     const int images = 2 * (LY * RY + 2 * M) * (TQ + 2 * ((M + 3) / 4)) * 16;
     const int ring = star_ring_quads(M, TQ, LY, RY, M + PF - 1) * 16;
+    // not in the separate-multiply-add order from radius 5 up: those kernels are bound by their arithmetic and registers, and
+    // measured 1-10 % slower with the ring's extra LDS traffic (radius 3: 7 % faster, radius 4: level)
+    if (ORDER == ORD_STAR_GOLDEN && M >= 5) return 0;
     return (M >= FDTDX_RING_MIN_M && !is_composite(ORDER) && images + ring <= 160 * 1024) ? M + PF - 1 : 0;
 }
 
