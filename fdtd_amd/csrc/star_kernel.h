@@ -123,7 +123,7 @@ template <int M, int TQ, int LY, int RY, int ORDER, int PF, int PH>
 __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], float4 (&eo)[RY],
                                            float4 (&hv)[star_nhk(M, TQ, LY, RY)], const Lane<RY, star_nhk(M, TQ, LY, RY)> &L,
                                            float4 *buf, float4 *ring, int &rslot, const float *&pn, const float *&pc, float *&po, const float *&pe,
-                                           long long ep, bool more_n, bool more_c,
+                                           long long ep, bool more_n, bool more_c, bool more_h,
                                            unsigned plane_bytes, const float (&c)[7], Comp<RY> &cs, int gz)
 {
     constexpr int HQ = (M + 3) / 4;
@@ -182,7 +182,8 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
         }
     }
 #pragma unroll
-    for (int k = 0; k < NHK; k++) hv[k] = buf_ld4(RP > 0 ? rn : rc, L.hgoff[k]);
+    for (int k = 0; k < NHK; k++)  // ring: only planes that become a centre plane of this chunk need their halo
+        hv[k] = RP > 0 ? buf_ld4(rn, more_h ? L.hgoff[k] : OOB) : buf_ld4(rc, L.hgoff[k]);
 #pragma unroll
     for (int j = 0; j < RY; j++)  // streamed past the caches where measured faster: full-row tiles (+2-4 % at radius 1 and 3; 3 % slower with x tiles)
         eo[j] = (is_composite(ORDER) || TQ >= 128) ? buf_ld4s(ron, L.eoff[j]) : buf_ld4(ron, L.eoff[j]);
@@ -428,11 +429,11 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
             for (int k = 0; k < NHK; k++) {
                 const int hidx = t + k * NT;
                 ring[(k < NHK - 1 || hidx < NHQ) ? i * NHQ + hidx : RP * NHQ + hidx - NHQ] =
-                    buf_ld4(make_rsrc(pc + (long long)i * p.plane, (zs + i < zlast) ? plane_bytes : 0u), L.hgoff[k]);
+                    buf_ld4(make_rsrc(pc + (long long)i * p.plane, (zs + i < ze) ? plane_bytes : 0u), L.hgoff[k]);
             }
 #pragma unroll
         for (int k = 0; k < NHK; k++)
-            hv[k] = buf_ld4(make_rsrc(pc + (long long)RP * p.plane, (zs + RP < zlast) ? plane_bytes : 0u), L.hgoff[k]);
+            hv[k] = buf_ld4(make_rsrc(pc + (long long)RP * p.plane, (zs + RP < ze) ? plane_bytes : 0u), L.hgoff[k]);
     } else {
 #pragma unroll
         for (int k = 0; k < NHK; k++) hv[k] = buf_ld4(make_rsrc(pc, plane_bytes), L.hgoff[k]);
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
     while (z < ze) {
         unroll_phases<0, QT>([&](auto ph) {
             if (z < ze) {
-                plane_step<M, TQ, LY, RY, ORDER, PF, decltype(ph)::value>(q, eo, hv, L, lds[par], ring, rslot, pn, pc, po, pe, ep, z < zn_end, z + 1 < ze,
+                plane_step<M, TQ, LY, RY, ORDER, PF, decltype(ph)::value>(q, eo, hv, L, lds[par], ring, rslot, pn, pc, po, pe, ep, z < zn_end, z + 1 < ze, z + M + PF < ze,
                                                                         plane_bytes, c, cs, p.zg0 + z);
                 par ^= 1;
 #ifdef FDTDX_DRIFT_PROBE
