@@ -98,6 +98,11 @@ class HipSlabBackend:
         if z_hi > z_lo:
             self.st.mulAcc(s, a, b, radius, order, z_lo, z_hi, torch.cuda.current_stream().cuda_stream)
 
+    def yee_half(self, fields, which, coef, order, z_lo, z_hi):
+        """One half step of the staggered-grid extension on planes [z_lo, z_hi) (fdtdx_yee3d_half)."""
+        if z_hi > z_lo:
+            self.st.yee3dHalf(fields, which, coef, order, z_lo, z_hi, torch.cuda.current_stream().cuda_stream)
+
     def can_fuse(self, program):
         """Deepest fusion the library has a kernel for (0: none)."""
         if program.kind == _lib.SPC13:
@@ -313,6 +318,112 @@ class CompositeRunner:
             self.step(s0, s1, vel, total)
             s0, s1 = s1, s0
         return s0, s1  # as main.cu leaves them after its swaps
+
+
+class YeeRunner:
+    """EXTENSION (no counterpart in the reference): the six-field staggered-grid step on z-slabs with one ghost
+    plane per side.  A step is two half steps, and each half reads z differences of two fields of the other
+    triple in ONE direction only:
+        H half (which 0)  H -= ch curl E, forward differences:  reads Ex, Ey of plane z+1
+        E half (which 1)  E += ce curl H, backward differences: reads Hx, Hy of plane z-1
+    so after the H half a rank's last owned plane of Hx, Hy goes up (into the upper neighbour's low ghost plane), and
+    after the E half its first owned plane of Ex, Ey goes down: two planes per half step and neighbour instead of the
+    six a both-ways exchange of the whole triple would move.  Ez and Hz are never differenced along z; their ghost
+    planes are not kept current.  As in SlabRunner, the plane that is sent is computed first and travels beside the
+    sweep of the remaining planes.
+
+    exchange: "device" / "host" / "none" as SlabRunner; "local": the neighbours are backends of this process
+    (`peers[rank]`, cubes of the same names on the same GPU or on peers with access) and planes move by device copies."""
+
+    def __init__(self, backend, names, rank, nprocs, group=None, exchange="device", order=_lib.ORDER_CHAIN, peers=None):
+        if len(names) != 6:
+            raise ValueError("six cube names: ex, ey, ez, hx, hy, hz")
+        self.b, self.names, self.order = backend, tuple(names), order
+        self.rank, self.nprocs, self.group, self.exchange, self.peers = rank, nprocs, group, exchange, peers or {}
+        g = backend.g
+        if (int(g.ghost_lo), int(g.ghost_hi)) not in ((0, 0), (1, 0), (0, 1), (1, 1)):
+            raise ValueError("the staggered-grid step runs on slabs with one ghost plane per neighbour (context created with M = 1)")
+        self.local = int(g.local_planes)
+        self.has_lo, self.has_hi = int(g.ghost_lo) > 0, int(g.ghost_hi) > 0
+        self.z_lo = 1                   # first plane updated: the first owned one, or plane 1 of the grid (shell untouched)
+        self.z_hi = self.local - 1
+        self._ops = {}
+
+    def _moves(self, which):
+        """(cube, plane sent, to rank, ghost plane received, from rank) of one half step; None where there is no neighbour."""
+        if which == 0:
+            cubes, send, dst, recv, src = self.names[3:5], self.local - 2, self.rank + 1, 0, self.rank - 1
+            do_send, do_recv = self.has_hi, self.has_lo
+        else:
+            cubes, send, dst, recv, src = self.names[0:2], 1, self.rank - 1, self.local - 1, self.rank + 1
+            do_send, do_recv = self.has_lo, self.has_hi
+        return cubes, (send, dst) if do_send else None, (recv, src) if do_recv else None
+
+    def _start_exchange(self, which):
+        if self.exchange == "none":
+            return []
+        cubes, snd, rcv = self._moves(which)
+        if self.exchange == "local":
+            if snd:
+                peer = self.peers[snd[1]]
+                ghost = 0 if which == 0 else int(peer.g.local_planes) - 1
+                for n in cubes:
+                    peer.planes(n, ghost, 1).copy_(self.b.planes(n, snd[0], 1))
+            return []
+        if which not in self._ops:
+            ops = []
+            for n in cubes:
+                if snd:
+                    ops.append(dist.P2POp(dist.isend, self.b.planes(n, snd[0], 1), snd[1], self.group))
+                if rcv:
+                    ops.append(dist.P2POp(dist.irecv, self.b.planes(n, rcv[0], 1), rcv[1], self.group))
+            self._ops[which] = ops
+        ops = self._ops[which]
+        if not ops:
+            return []
+        if self.exchange == "device":
+            return dist.batch_isend_irecv(ops)
+        staged, cpu_ops = [], []
+        for op in ops:
+            t = op.tensor
+            h = t.cpu() if op.op is dist.isend else torch.empty(t.shape, dtype=t.dtype)
+            cpu_ops.append(dist.P2POp(op.op, h, op.peer, op.group))
+            if op.op is dist.irecv:
+                staged.append((t, h))
+        reqs = dist.batch_isend_irecv(cpu_ops)
+
+        class _Staged:
+            def wait(self_inner):
+                for r in reqs:
+                    r.wait()
+                for t, h in staged:
+                    t.copy_(h)
+        return [_Staged()]
+
+    def half(self, which, coef):
+        lo, hi = self.z_lo, self.z_hi
+        _, snd, _ = self._moves(which)
+        if snd and hi > lo:
+            z = snd[0]                  # the plane the neighbour waits for: first, so that it travels beside the rest
+            self.b.yee_half(self.names, which, coef, self.order, z, z + 1)
+            reqs = self._start_exchange(which)
+            if z == lo:
+                self.b.yee_half(self.names, which, coef, self.order, lo + 1, hi)
+            else:
+                self.b.yee_half(self.names, which, coef, self.order, lo, hi - 1)
+        else:
+            self.b.yee_half(self.names, which, coef, self.order, lo, hi)
+            reqs = self._start_exchange(which)
+        for r in reqs:
+            r.wait()
+
+    def step(self, ce, ch):
+        self.half(0, ch)
+        self.half(1, ce)
+
+    def run(self, steps, ce, ch):
+        for _ in range(steps):
+            self.step(ce, ch)
 
 
 def gather_cube(backend, name, Z, Y, X, rank, nprocs, group=None):

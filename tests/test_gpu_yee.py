@@ -121,3 +121,33 @@ def test_yee2d_equals_its_cpu_definition(oracle_cpu, shape, order):
         oracle_cpu.yee2d_step(ex, ey, hz, t, 0.5, 0.7, order=ORD[order])
     for name, d, r in zip(("ex", "ey", "hz"), dev, (ex, ey, hz)):
         assert np.array_equal(d.cpu().numpy().view(np.uint32), r.view(np.uint32)), name
+
+
+@pytest.mark.parametrize("nslabs,shape,steps,order", [(2, (20, 37, 260), 4, ORDER_CHAIN), (3, (23, 14, 70), 5, ORDER_GOLDEN),
+                                                      (4, (256, 256, 256), 3, ORDER_CHAIN)])
+def test_yee3d_on_z_slabs_equals_undecomposed(nslabs, shape, steps, order):
+    """The six-field step cut into z-slabs (fdtd_amd/slab.py:YeeRunner): the ranks of an nslabs-way split run in
+    this one process on the one GPU and hand their boundary planes to each other by device copies (after the H half
+    Hx, Hy go up, after the E half Ex, Ey go down).  The gathered fields equal the undecomposed run bit for bit."""
+    from fdtd_amd.slab import HipSlabBackend, YeeRunner
+    Z, Y, X = shape
+    f = fields(shape, seed=8)
+    ref = gpu_yee3d(shape, f, steps, order)
+    bes = [HipSlabBackend(Z, Y, X, 1, r, nslabs, 0) for r in range(nslabs)]
+    for be in bes:
+        lo, n = int(be.g.first_global), int(be.g.local_planes)
+        for name, a in zip(NAMES, f):
+            be.alloc(name)
+            be.st.uploadLocal(name, np.ascontiguousarray(a[lo:lo + n]))
+    peers = dict(enumerate(bes))
+    runs = [YeeRunner(be, NAMES, r, nslabs, exchange="local", order=order, peers=peers) for r, be in enumerate(bes)]
+    for _ in range(steps):
+        for which, coef in ((0, 0.27), (1, 0.31)):
+            for run in runs:
+                run.half(which, coef)
+    torch.cuda.synchronize()
+    for name, r in zip(NAMES, ref):
+        got = np.concatenate([be.st.downloadOwned(name) for be in bes], axis=0)
+        assert np.array_equal(got.view(np.uint32), r.view(np.uint32)), name
+    for be in bes:
+        be.st.close()

@@ -118,6 +118,14 @@ class OracleSlabBackend:
         self.cpu.mul_acc(dst, self._get(a), self._get(b), M=radius, order=1 - order, z_lo=z_lo, z_hi=z_hi)
         self._put(s, dst, z_lo, z_hi)
 
+    def yee_half(self, fields, which, coef, order, z_lo, z_hi):
+        if z_hi <= z_lo:
+            return
+        f = [self._get(n) for n in fields]
+        self.cpu.yee3d_half(f, which, coef, order=1 - order, z_lo=z_lo, z_hi=z_hi)
+        for n, a in zip(fields[3:] if which == 0 else fields[:3], f[3:] if which == 0 else f[:3]):
+            self._put(n, a, z_lo, z_hi)
+
     def copy_cube(self, dst, src):
         self.bufs[dst].copy_(self.bufs[src])
 
@@ -206,6 +214,59 @@ def test_composite_pipeline_decomposition_invariance(oracle_cpu, world, shape, s
         p0, p1 = p1, p0
     for gfield, ref in zip(got, (p0, p1, s)):
         assert np.array_equal(gfield.view(np.uint32), ref.view(np.uint32))
+
+
+YEE = ("ex", "ey", "ez", "hx", "hy", "hz")
+
+
+def _yee_fields(shape):
+    rng = np.random.default_rng(5)
+    return [rng.random(shape, dtype=np.float32) for _ in range(6)]
+
+
+def _yee_worker(rank, world, port, shape, steps, order, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import cpu
+    from fdtd_amd.slab import YeeRunner
+    Z, Y, X = shape
+    be = OracleSlabBackend(cpu, Z, Y, X, 1, rank, world)
+    g = be.g
+    lo, n = int(g.first_global), int(g.local_planes)
+    for name, arr in zip(YEE, _yee_fields(shape)):
+        be.alloc(name)
+        be.upload_local(name, arr[lo:lo + n])
+    YeeRunner(be, YEE, rank, world, order=order).run(steps, 0.31, 0.27)
+    o0, o1 = int(g.ghost_lo), int(g.ghost_lo) + int(g.owned_planes)
+    q.put((rank, int(g.owned_begin), [be.view3(nm)[o0:o1, :, :X].copy() for nm in YEE]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape,steps,order", [(2, (12, 7, 9), 4, lib.ORDER_CHAIN), (3, (17, 6, 8), 3, lib.ORDER_GOLDEN)])
+def test_staggered_grid_step_decomposition_invariance(oracle_cpu, world, shape, steps, order):
+    """EXTENSION, no reference oracle: the six-field E/H step on z-slabs (fdtd_amd/slab.py:YeeRunner; after each
+    half step two fields move one plane in one direction) equals the undecomposed step of its CPU definition."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_yee_worker, args=(r, world, port, shape, steps, order, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    parts = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got = [np.zeros(shape, np.float32) for _ in range(6)]
+    for rank, begin, fields in parts:
+        for gfield, f in zip(got, fields):
+            gfield[begin:begin + f.shape[0]] = f
+    ref = _yee_fields(shape)
+    for _ in range(steps):
+        oracle_cpu.yee3d_step(ref, 0.31, 0.27, order=1 - order)
+    for name, gfield, r in zip(YEE, got, ref):
+        assert np.array_equal(gfield.view(np.uint32), r.view(np.uint32)), name
 
 
 def _free_port():
