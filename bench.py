@@ -331,12 +331,43 @@ def main():
         nl = steps if (kind == "yee3d" and a.temporal) else 2 * steps
         return dict(dt=dt, ev_ms=e0.elapsed_time(e1), cells_rank=cells, cells_all=cells, info=info, kind=kind, radius=1, launches=nl)
 
+    def time_yee_slabs(steps, warmup):
+        """The E/H extension on z-slabs, one per rank (fdtd_amd/slab.py:YeeRunner): two half-step launches per rank and step,
+        after each half two fields move one plane to one neighbour.  Random fields per rank: the ghost planes do not match
+        the neighbours' at the start, which the timing does not see."""
+        from fdtd_amd.slab import YeeRunner
+        n = a.n
+        Zg = n * world
+        be = HipSlabBackend(Zg, n, n, 1, rank, world, local_rank)
+        names = ("ex", "ey", "ez", "hx", "hy", "hz")
+        for i, name in enumerate(names):
+            be.alloc(name).uniform_(0.0, 1.0, generator=torch.Generator(device=be.device).manual_seed(6 * rank + i))
+        run = YeeRunner(be, names, rank, world, exchange="host" if a.rehearse_shared_gpu else "device")
+        loop = lambda k: run.run(k, 0.31, 0.27)
+        spin_up(loop, [be.bufs[nm] for nm in names])
+        loop(warmup)
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        loop(steps)
+        e1.record()
+        barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        cells_rank = float(run.z_hi - run.z_lo) * float(n - 2) ** 2
+        be.st.close()
+        return dict(dt=float(t.item()), ev_ms=e0.elapsed_time(e1), cells_rank=cells_rank, cells_all=float(Zg - 2) * float(n - 2) ** 2,
+                    info="yee3d_half_kernel x2 per step and rank; Hx, Hy one plane up after the H half, Ex, Ey one plane down after the E half",
+                    kind="yee3d", radius=1, launches=4 * steps, bpu=72.0, slabs=True)
+
     def time_variant(name, steps, warmup):
         kind, radius, _ = VARIANTS[name]
         if kind in ("yee3d", "yee2d"):
-            if world != 1:
-                raise SystemExit("the E/H extension variants run on one rank")
-            return time_yee(kind, steps, warmup)
+            if world != 1 and kind == "yee2d":
+                raise SystemExit("--variant yee2d runs on one rank")
+            return time_yee_slabs(steps, warmup) if world != 1 else time_yee(kind, steps, warmup)
         if kind == "composite":
             if world != 1:
                 raise SystemExit("--variant main runs on one rank")
@@ -486,6 +517,7 @@ def main():
         value = r["cells_all"] * steps / r["dt"] * 1e-9
         # bytes per cell-step: sweeps 8; main 24 (one fused step); yee3d 48 in one launch (72 as two half steps), yee2d 36 as two launches
         bpu = {"composite": BYTES_PER_UPDATE_MAIN, "yee3d": 48.0 if a.temporal else 72.0, "yee2d": 36.0}.get(r["kind"], BYTES_PER_UPDATE)
+        bpu = r.get("bpu", bpu)
         if "kernel_us" in r:
             launch_s, spl, navg = r["kernel_us"] * 1e-6, float(r["kernel_steps"]), r["kernel_launches"]
         else:
@@ -532,7 +564,8 @@ def main():
         grid = [int(v) for v in a.grid.split(",")]
     if r["kind"] == "yee3d":
         workload = (f"yee3d (extension): six-field E/H step = H half step + E half step "
-                    f"({'one fused launch' if a.temporal else 'two launches'}), {a.n}^3 fp32 grid, {a.steps} steps")
+                    f"({'one fused launch' if (a.temporal and not r.get('slabs')) else 'two launches'}), "
+                    + (f"{a.n * world}x{a.n}x{a.n} fp32 grid in {world} z-slabs" if r.get("slabs") else f"{a.n}^3 fp32 grid") + f", {a.steps} steps")
     elif r["kind"] == "yee2d":
         workload = f"yee2d (extension): ex/ey/hz step on a {a.n}x{a.n} fp32 grid, {a.steps} steps"
     else:
@@ -577,7 +610,7 @@ def main():
         dist.all_gather_object(who, {"rank": rank, "device": local_rank, "name": torch.cuda.get_device_name(local_rank)})
         line["ranks"] = who
         line["config"]["exchange"] = ("host-staged gloo (rehearsal)" if a.rehearse_shared_gpu else
-                                      "RCCL send/recv issued by the library on its exchange stream (fdtdx_run)" if a.exchange == "native"
+                                      "RCCL send/recv issued by the library on its exchange stream (fdtdx_run)" if (a.exchange == "native" and not r.get("slabs"))
                                       else "torch.distributed batch_isend_irecv on the nccl (= RCCL) backend")
         line["config"]["world_size"] = dist.get_world_size()
         dist.barrier()
