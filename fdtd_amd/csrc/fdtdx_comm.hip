@@ -462,6 +462,81 @@ extern "C" int fdtdx_hop_begin(fdtdx_ctx *ctx, const char *out, const char *in, 
 
 extern "C" int fdtdx_step_end(fdtdx_ctx *ctx, void *stream) { return fdtdx_comm_exchange_wait(ctx, stream); }
 
+// ---- extension (no counterpart in the reference): one half step of the six-field E/H update on a slab with neighbours --
+// The H half differences Ex, Ey forwards along z and the E half differences Hx, Hy backwards, so what a neighbour needs of a
+// half step's result is ONE plane of TWO fields, in ONE direction: Hx, Hy of the last owned plane go up, Ex, Ey of the first
+// owned plane go down.  That plane is updated first, the two copies (or sends) start behind it on the exchange stream and
+// the remaining planes are updated beside them; fdtdx_step_end makes the caller's stream wait for the planes received.
+// Ez and Hz ghost planes are never read and stay as they are.
+extern "C" int fdtdx_yee3d_slab_half_begin(fdtdx_ctx *ctx, const char *const fields[6], int which, float coef, uint32_t order, void *stream)
+{
+    if (!ctx || !fields) return fail(FDTDX_ERR_INVALID, "null argument");
+    if (which != 0 && which != 1) return fail(FDTDX_ERR_INVALID, "which must be 0 (H half step) or 1 (E half step)");
+    const fdtdx_geometry &g = ctx->g;
+    if (g.ghost_lo > 1 || g.ghost_hi > 1) return fail(FDTDX_ERR_UNSUPPORTED, "the E/H step runs on slabs with one ghost plane per neighbour (context created with M = 1)");
+    if (g.local_planes < 3) return FDTDX_OK;
+    const uint64_t lo = 1, hi = g.local_planes - 1;
+    fdtdx_comm *c = ctx->comm;
+    if (!c) {
+        if (ctx->cfg.nprocs != 1) return fail(FDTDX_ERR_INVALID, "no communicator: call fdtdx_comm_init or fdtdx_comm_init_local first");
+        return fdtdx_yee3d_half(ctx, fields, which, coef, order, lo, hi, stream);
+    }
+    if (c->epoch != c->waited) return fail(FDTDX_ERR_INVALID, "the previous exchange has not been waited for (fdtdx_step_end)");
+    const int s = which == 0 ? 1 : 0;                                   // the side the plane travels to: up after the H half, down after the E half
+    const bool snd = s ? g.ghost_hi != 0 : g.ghost_lo != 0, rcv = s ? g.ghost_lo != 0 : g.ghost_hi != 0;
+    const uint64_t zs = s ? g.local_planes - 2 : 1;                     // the owned plane next to that neighbour
+    const uint64_t zr = s ? 0 : g.local_planes - 1;                     // the ghost plane the other neighbour fills
+    float *cube[2];
+    int rc;
+    for (int k = 0; k < 2; k++)
+        if ((rc = fdtdx_find_cube(ctx, fields[(which == 0 ? 3 : 0) + k], &cube[k]))) return rc;
+    if (snd && (rc = fdtdx_yee3d_half(ctx, fields, which, coef, order, zs, zs + 1, stream))) return rc;
+    USE_DEVICE(ctx);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipEventRecord(c->ready, st));
+    submit_now(st);
+    c->marked = false;
+    HIP_TRY(hipStreamWaitEvent(c->xs, c->ready, 0));
+    const size_t cnt = (size_t)g.plane;
+    if (c->mode == COMM_RCCL) {
+        RcclApi *api;
+        if ((rc = rccl(&api))) return rc;
+        NCCL_TRY(api, api->GroupStart());
+        for (int k = 0; k < 2; k++) {
+            if (snd) NCCL_TRY(api, api->Send(cube[k] + zs * g.plane, cnt, ncclFloat, c->peer[s], c->comm, c->xs));
+            if (rcv) NCCL_TRY(api, api->Recv(cube[k] + zr * g.plane, cnt, ncclFloat, c->peer[1 - s], c->comm, c->xs));
+        }
+        NCCL_TRY(api, api->GroupEnd());
+    } else if (snd) {
+        fdtdx_ctx *o = c->nb[s];
+        if (!o || !o->comm) return fail(FDTDX_ERR_INVALID, "the neighbouring slab is gone");
+        if (o->g.plane != g.plane) return fail(FDTDX_ERR_INVALID, "the neighbouring slab has another geometry");
+        // the neighbour's launches queued so far may still read the ghost plane the copies land in
+        if (o->comm->last_stream || o->comm->epoch) {
+            HIP_TRY(hipSetDevice(o->device));
+            HIP_TRY(hipEventRecord(o->comm->guard[1 - s], o->comm->last_stream));
+            submit_now(o->comm->last_stream);
+            HIP_TRY(hipSetDevice(ctx->device));
+            HIP_TRY(hipStreamWaitEvent(c->xs, o->comm->guard[1 - s], 0));
+        }
+        const uint64_t zd = s ? 0 : o->g.local_planes - 1;              // its ghost plane on the side that faces this slab
+        for (int k = 0; k < 2; k++) {
+            float *dst;
+            if ((rc = fdtdx_find_cube(o, fields[(which == 0 ? 3 : 0) + k], &dst))) return rc;
+            if (o->device == ctx->device)
+                HIP_TRY(hipMemcpyAsync(dst + zd * g.plane, cube[k] + zs * g.plane, cnt * sizeof(float), hipMemcpyDeviceToDevice, c->xs));
+            else
+                HIP_TRY(hipMemcpyPeerAsync(dst + zd * g.plane, o->device, cube[k] + zs * g.plane, ctx->device, cnt * sizeof(float), c->xs));
+        }
+    }
+    HIP_TRY(hipEventRecord(c->done, c->xs));
+    submit_now(c->xs);
+    c->last_stream = st;
+    c->epoch++;
+    const uint64_t rlo = (snd && !s) ? lo + 1 : lo, rhi = (snd && s) ? hi - 1 : hi;
+    return rhi > rlo ? fdtdx_yee3d_half(ctx, fields, which, coef, order, rlo, rhi, stream) : FDTDX_OK;
+}
+
 // The drivers' whole loop on n slabs (fdtd1.cu:68-80): n = 1 for a process that owns one slab and talks to the others
 // through its RCCL communicator, n = all slabs for a process that owns them all.  Level t lives in b for even t and in a
 // for odd t; fused launches where the ghost depth allows them; the last steps are single steps, so that a and b finish

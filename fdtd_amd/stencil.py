@@ -226,6 +226,11 @@ class Stencil:
             z_lo, z_hi = 1, int(self.geometry.local_planes) - 1
         _lib.check(self._L.fdtdx_yee3d_half(self._h, self._names(fields), which, coef, order, z_lo, z_hi, ctypes.c_void_p(stream or 0)))
 
+    def yee3dSlabHalfBegin(self, fields, which, coef, order=_lib.ORDER_CHAIN, stream=None):
+        """One half step on a slab with neighbours: the plane a neighbour needs first, its exchange, the rest beside it;
+        stepEnd() waits for the planes received (slabs of one process: begin on all, then end on all)."""
+        _lib.check(self._L.fdtdx_yee3d_slab_half_begin(self._h, self._names(fields), which, coef, order, ctypes.c_void_p(stream or 0)))
+
     def yee3dStep(self, fields, ce, ch, order=_lib.ORDER_CHAIN, stream=None):
         _lib.check(self._L.fdtdx_yee3d_step(self._h, self._names(fields), ce, ch, order, ctypes.c_void_p(stream or 0)))
 

@@ -334,6 +334,14 @@ int fdtdx_yee3d_step(fdtdx_ctx *ctx, const char *const fields[6], float ce, floa
  * ping-pongs between the two sets.  Results equal fdtdx_yee3d_step bit for bit.  Extension like the half steps. */
 int fdtdx_yee3d_step_fused(fdtdx_ctx *ctx, const char *const before[6], const char *const after[6], float ce, float ch,
                            uint32_t order, void *stream);
+/* One half step on a slab with neighbours (contexts created with M = 1 and a communicator): the one owned plane a
+ * neighbour needs is updated first (which = 0: Hx, Hy of the last owned plane, for the slab above; which = 1: Ex, Ey of
+ * the first owned plane, for the slab below), its two cubes' planes start towards that neighbour's ghost plane on the
+ * exchange stream, the remaining planes are updated beside that.  fdtdx_step_end makes `stream` wait for the planes this
+ * slab receives.  Slabs of one process: begin on every slab, then end on every slab.  Ez / Hz ghost planes are not kept
+ * current (nothing differences them along z).  No counterpart in the reference. */
+int fdtdx_yee3d_slab_half_begin(fdtdx_ctx *ctx, const char *const fields[6], int which, float coef, uint32_t order,
+                                void *stream);
 /* 2-D ex/ey/hz on dense [nx][ny] device arrays (ny fastest), `steps` steps numbered t0, t0+1, ...:
  *   ey[0][j] = t;  ey[i][j] -= ce*(hz[i][j]-hz[i-1][j]) (i>=1);  ex[i][j] -= ce*(hz[i][j]-hz[i][j-1]) (j>=1);
  *   hz[i][j] -= ch*(((ex[i][j+1]-ex[i][j]) + ey[i+1][j]) - ey[i][j])  (i<nx-1, j<ny-1). */

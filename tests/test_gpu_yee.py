@@ -151,3 +151,38 @@ def test_yee3d_on_z_slabs_equals_undecomposed(nslabs, shape, steps, order):
         assert np.array_equal(got.view(np.uint32), r.view(np.uint32)), name
     for be in bes:
         be.st.close()
+
+
+@pytest.mark.parametrize("own_streams", [False, True], ids=["default-stream", "stream-per-slab"])
+@pytest.mark.parametrize("nslabs,shape,steps,order", [(2, (20, 37, 260), 4, ORDER_CHAIN), (3, (23, 14, 70), 5, ORDER_GOLDEN),
+                                                      (4, (256, 256, 256), 3, ORDER_CHAIN)])
+def test_yee3d_native_slab_half_steps_equal_undecomposed(nslabs, shape, steps, order, own_streams):
+    """fdtdx_yee3d_slab_half_begin / fdtdx_step_end: the library itself updates the plane a neighbour needs first, moves
+    it (slabs of this process: device copies on its exchange streams) and updates the rest beside that.  Equal to the
+    undecomposed run bit for bit, on the default stream and with a stream per slab."""
+    Z, Y, X = shape
+    f = fields(shape, seed=9)
+    ref = gpu_yee3d(shape, f, steps, order)
+    slabs = []
+    for r in range(nslabs):
+        st = Stencil(Z, Y, X, 1, rank=r, nprocs=nslabs, device=0)
+        lo, n = int(st.geometry.first_global), int(st.geometry.local_planes)
+        for name, a in zip(NAMES, f):
+            st.mallocCube(name)
+            st.uploadLocal(name, np.ascontiguousarray(a[lo:lo + n]))
+        slabs.append(st)
+    Stencil.commInitLocal(slabs)
+    streams = [torch.cuda.Stream() for _ in slabs] if own_streams else None
+    cs = [s.cuda_stream for s in streams] if streams else [None] * nslabs
+    for _ in range(steps):
+        for which, coef in ((0, 0.27), (1, 0.31)):
+            for st, s in zip(slabs, cs):
+                st.yee3dSlabHalfBegin(NAMES, which, coef, order, s)
+            for st, s in zip(slabs, cs):
+                st.stepEnd(s)
+    torch.cuda.synchronize()
+    for name, r in zip(NAMES, ref):
+        got = np.concatenate([st.downloadOwned(name) for st in slabs], axis=0)
+        assert np.array_equal(got.view(np.uint32), r.view(np.uint32)), name
+    for st in slabs:
+        st.close()
