@@ -186,3 +186,51 @@ def test_yee3d_native_slab_half_steps_equal_undecomposed(nslabs, shape, steps, o
         assert np.array_equal(got.view(np.uint32), r.view(np.uint32)), name
     for st in slabs:
         st.close()
+
+
+def test_yee3d_slab_half_step_over_rccl_loop_back():
+    """A middle slab whose two neighbours are itself (a communicator of one): the real ncclSend/ncclRecv group of
+    fdtdx_yee3d_slab_half_begin on the exchange stream.  The plane sent up comes back into the low ghost plane, the plane
+    sent down into the high one; the update itself equals fdtdx_yee3d_half on the same planes; Ez / Hz ghosts stay."""
+    Z, Y, X = 40, 21, 130
+    f = fields((Z, Y, X), seed=12)
+    cs = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for native in (False, True):
+        with Stencil(Z, Y, X, 1, rank=1, nprocs=3, device=0) as st:
+            lo, L = int(st.geometry.first_global), int(st.geometry.local_planes)
+            for name, a in zip(NAMES, f):
+                st.mallocCube(name)
+                st.uploadLocal(name, np.ascontiguousarray(a[lo:lo + L]))
+            if native:
+                st.commInit(Stencil.commUniqueId(), comm_rank=0, comm_size=1, peer_lo=0, peer_hi=0)
+            res = []
+            for which, coef in ((0, 0.27), (1, 0.31)):
+                if native:
+                    st.yee3dSlabHalfBegin(NAMES, which, coef, ORDER_CHAIN, cs)
+                    st.stepEnd(cs)
+                else:
+                    st.yee3dHalf(NAMES, which, coef, ORDER_CHAIN, 1, L - 1, cs)
+                st.sync()
+                P = int(st.geometry.plane)
+                snap = [torch.as_tensor(_CAI(st.getCube(n), L * P), device="cuda").view(L, P).clone() for n in NAMES]
+                res.append(snap)
+            out[native] = res
+    for h, (plain, nat) in enumerate(zip(out[False], out[True])):
+        for i, (p, q) in enumerate(zip(plain, nat)):
+            # owned planes: the same update (the E half's first owned plane differences the low ghost of Hx, Hy, which
+            # only the exchanging run has filled with the new values)
+            assert torch.equal(p[1 + h:-1], q[1 + h:-1]), (h, NAMES[i])
+    L = out[True][0][0].shape[0]
+    for i in (3, 4):                                                        # Hx, Hy: last owned plane -> low ghost, after the H half
+        assert torch.equal(out[True][0][i][0], out[True][0][i][L - 2])
+        assert torch.equal(out[True][0][i][L - 1], out[False][0][i][L - 1])
+    for i in (0, 1):                                                        # Ex, Ey: first owned plane -> high ghost, after the E half
+        assert torch.equal(out[True][1][i][L - 1], out[True][1][i][1])
+    for i in (2, 5):                                                        # Ez, Hz ghosts untouched
+        assert torch.equal(out[True][1][i][0], out[False][1][i][0]) and torch.equal(out[True][1][i][L - 1], out[False][1][i][L - 1])
+
+
+class _CAI:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
