@@ -342,7 +342,27 @@ def main():
         names = ("ex", "ey", "ez", "hx", "hy", "hz")
         for i, name in enumerate(names):
             be.alloc(name).uniform_(0.0, 1.0, generator=torch.Generator(device=be.device).manual_seed(6 * rank + i))
-        run = YeeRunner(be, names, rank, world, exchange="host" if a.rehearse_shared_gpu else "device")
+        mode = "host" if a.rehearse_shared_gpu else "device"
+        if a.exchange == "native" and not a.rehearse_shared_gpu:
+            # the library's own communicator, as for the sweeps; every rank takes the same path
+            ok = torch.ones(1, device="cuda")
+            box = [None]
+            if rank == 0:
+                try:
+                    box = [Stencil.commUniqueId()]
+                except Exception as e:
+                    print(f"rank 0: no RCCL id ({e})", file=sys.stderr)
+            dist.broadcast_object_list(box, src=0)
+            try:
+                if box[0] is None:
+                    raise RuntimeError("rank 0 could not make a communicator id")
+                be.st.commInit(box[0])
+            except Exception as e:
+                print(f"rank {rank}: native exchange unavailable ({e})", file=sys.stderr)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            mode = "native" if ok.item() != 0 else "device"
+        run = YeeRunner(be, names, rank, world, exchange=mode)
         loop = lambda k: run.run(k, 0.31, 0.27)
         spin_up(loop, [be.bufs[nm] for nm in names])
         loop(warmup)
@@ -360,7 +380,7 @@ def main():
         be.st.close()
         return dict(dt=float(t.item()), ev_ms=e0.elapsed_time(e1), cells_rank=cells_rank, cells_all=float(Zg - 2) * float(n - 2) ** 2,
                     info="yee3d_half_kernel x2 per step and rank; Hx, Hy one plane up after the H half, Ex, Ey one plane down after the E half",
-                    kind="yee3d", radius=1, launches=4 * steps, bpu=72.0, slabs=True)
+                    kind="yee3d", radius=1, launches=4 * steps, bpu=72.0, slabs=True, exchange=mode)
 
     def time_variant(name, steps, warmup):
         kind, radius, _ = VARIANTS[name]
@@ -610,7 +630,7 @@ def main():
         dist.all_gather_object(who, {"rank": rank, "device": local_rank, "name": torch.cuda.get_device_name(local_rank)})
         line["ranks"] = who
         line["config"]["exchange"] = ("host-staged gloo (rehearsal)" if a.rehearse_shared_gpu else
-                                      "RCCL send/recv issued by the library on its exchange stream (fdtdx_run)" if (a.exchange == "native" and not r.get("slabs"))
+                                      "RCCL send/recv issued by the library on its exchange stream" if (a.exchange == "native" and r.get("exchange", "native") == "native")
                                       else "torch.distributed batch_isend_irecv on the nccl (= RCCL) backend")
         line["config"]["world_size"] = dist.get_world_size()
         dist.barrier()

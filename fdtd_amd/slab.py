@@ -332,7 +332,9 @@ class YeeRunner:
     planes are not kept current.  As in SlabRunner, the plane that is sent is computed first and travels beside the
     sweep of the remaining planes.
 
-    exchange: "device" / "host" / "none" as SlabRunner; "local": the neighbours are backends of this process
+    exchange: "device" / "host" / "none" as SlabRunner; "native": split and exchange inside the library, over its own
+    communicator (half_begin / half_end; slabs of one process call begin on every slab, then end on every slab);
+    "local": the neighbours are backends of this process
     (`peers[rank]`, cubes of the same names on the same GPU or on peers with access) and planes move by device copies."""
 
     def __init__(self, backend, names, rank, nprocs, group=None, exchange="device", order=_lib.ORDER_CHAIN, peers=None):
@@ -400,7 +402,19 @@ class YeeRunner:
                     t.copy_(h)
         return [_Staged()]
 
+    def half_begin(self, which, coef):
+        """exchange="native": the library's own split and exchange (fdtdx_yee3d_slab_half_begin; the context has a
+        communicator: Stencil.commInit, or commInitLocal for slabs of one process)."""
+        self.b.st.yee3dSlabHalfBegin(self.names, which, coef, self.order, torch.cuda.current_stream().cuda_stream)
+
+    def half_end(self):
+        self.b.st.stepEnd(torch.cuda.current_stream().cuda_stream)
+
     def half(self, which, coef):
+        if self.exchange == "native":
+            self.half_begin(which, coef)
+            self.half_end()
+            return
         lo, hi = self.z_lo, self.z_hi
         _, snd, _ = self._moves(which)
         if snd and hi > lo:

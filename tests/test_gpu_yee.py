@@ -234,3 +234,32 @@ def test_yee3d_slab_half_step_over_rccl_loop_back():
 class _CAI:
     def __init__(self, ptr, n):
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+def test_yee_runner_native_exchange_on_local_slabs():
+    """fdtd_amd/slab.py:YeeRunner(exchange="native") is the library's own split (half_begin on every slab, then half_end)."""
+    from fdtd_amd.slab import HipSlabBackend, YeeRunner
+    shape, nslabs, steps = (26, 19, 140), 3, 4
+    Z, Y, X = shape
+    f = fields(shape, seed=10)
+    ref = gpu_yee3d(shape, f, steps, ORDER_CHAIN)
+    bes = [HipSlabBackend(Z, Y, X, 1, r, nslabs, 0) for r in range(nslabs)]
+    for be in bes:
+        lo, n = int(be.g.first_global), int(be.g.local_planes)
+        for name, a in zip(NAMES, f):
+            be.alloc(name)
+            be.st.uploadLocal(name, np.ascontiguousarray(a[lo:lo + n]))
+    Stencil.commInitLocal([be.st for be in bes])
+    runs = [YeeRunner(be, NAMES, r, nslabs, exchange="native") for r, be in enumerate(bes)]
+    for _ in range(steps):
+        for which, coef in ((0, 0.27), (1, 0.31)):
+            for run in runs:
+                run.half_begin(which, coef)
+            for run in runs:
+                run.half_end()
+    torch.cuda.synchronize()
+    for name, r in zip(NAMES, ref):
+        got = np.concatenate([be.st.downloadOwned(name) for be in bes], axis=0)
+        assert np.array_equal(got.view(np.uint32), r.view(np.uint32)), name
+    for be in bes:
+        be.st.close()
