@@ -150,6 +150,11 @@ extern "C" int fdtdx_create(const fdtdx_config *cfg, fdtdx_ctx **out)
     c->cfg = *cfg;
     c->g = g;
     c->device = dev;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) c->num_cus = cus;
+        else (void)hipGetLastError();
+    }
     // set-up of the static scratch for this device (device `dev` is current here); a failure is kept for
     // fdtdx_composite_step_static to report, every other entry point works without the array
     if (scratch_address(dev, &c->static_scratch) != FDTDX_OK) c->static_scratch = nullptr;
@@ -515,11 +520,11 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
     const long long nz = std::max<long long>((long long)(z_hi - z_lo), n2);  // chunks are sized for the longer range
     long long chunks = ctx->opt_zchunks;
     if (chunks <= 0) {
-        // one workgroup per CU (256 CUs) measured fastest: every extra z chunk re-reads 2r planes
+        // one workgroup per CU (256 CUs on MI355X) measured fastest: every extra z chunk re-reads 2r planes
         // to fill its queue, so split z only as far as needed to cover the chip, and keep the
         // fill below ~1/6 of a chunk
         const long long tiles = (long long)gx * gy * (n2 ? 2 : 1);
-        const long long cus = std::max<long long>(1, 256 - ctx->opt_reserve_cus);
+        const long long cus = std::max<long long>(1, ctx->num_cus - ctx->opt_reserve_cus);
         chunks = std::max<long long>(1, cus / tiles);  // never more workgroups than CUs: a second round would run nearly empty
         if (threads <= 256) chunks *= 2;  // small workgroups: two per CU
         const long long min_len = std::max<long long>(12LL * r, 16);
@@ -611,6 +616,17 @@ bool fdtdx_has_fused(const fdtdx_ctx *ctx, const fdtdx_program *prog, int kt, bo
     return v && (!shells || v->shells);
 }
 
+extern "C" int fdtdx_fused_depth(const fdtdx_ctx *ctx, const fdtdx_program *prog, int named_shells)
+{
+    if (!ctx) return -fail(FDTDX_ERR_INVALID, "null context");
+    int r;
+    const int rc = check_program(ctx, prog, &r);
+    if (rc) return -rc;
+    for (int kt = 3; kt >= 2; kt--)
+        if (fdtdx_has_fused(ctx, prog, kt, named_shells != 0)) return kt;
+    return 0;
+}
+
 static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const float *in, const float *mid, const fdtdx_program *prog,
                      uint64_t z_lo, uint64_t z_hi, void *stream, const float *even = nullptr, uint64_t z2_lo = 0, uint64_t z2_hi = 0)
 {
@@ -661,11 +677,11 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
         long long chunks = ctx->opt_tb_zchunks;
         if (chunks <= 0) {
             // The fused kernel runs one workgroup per CU (registers, LDS), so N workgroups take
-            // ceil(N/256) rounds of the 256 CUs, and every chunk pays for filling its queues (the planes a
+            // ceil(N/CUs) rounds of the device's CUs, and every chunk pays for filling its queues (the planes a
             // launch reaches beyond its range are re-read, plus start-up: about 6 planes' worth in all, from
             // timings at 512^3 and 1024^3): take the chunk count with the best product of the two efficiencies.
             const long long tiles = (long long)q.gx * q.gy * (n2 ? 2 : 1);
-            const long long cus = std::max<long long>(1, 256 - ctx->opt_reserve_cus);
+            const long long cus = std::max<long long>(1, ctx->num_cus - ctx->opt_reserve_cus);
             double best = -1.0;
             chunks = 1;
             for (long long cnt = 1; cnt <= std::max<long long>(1, nz / 16) && cnt * tiles <= 4096; cnt++) {

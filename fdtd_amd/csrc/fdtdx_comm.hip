@@ -92,6 +92,7 @@ struct fdtdx_comm {
     hipEvent_t done = nullptr;      // recorded on xs: this context's part of the exchange has finished
     hipEvent_t guard[2] = {nullptr, nullptr};  // local: recorded on THIS context's stream for the neighbour on that side
     bool marked = false;            // `ready` was recorded explicitly (fdtdx_comm_boundary_done) for the next exchange
+    bool broken = false;            // an RCCL call failed inside a send/recv group: the communicator's state is unknown, every later exchange fails fast
     uint64_t epoch = 0;             // exchanges started
     uint64_t waited = 0;            // exchanges waited for
     hipStream_t last_stream = nullptr;
@@ -267,6 +268,7 @@ extern "C" int fdtdx_comm_exchange_start(fdtdx_ctx *ctx, const char *name, void 
     if (!ctx || !name) return fail(FDTDX_ERR_INVALID, "null argument");
     fdtdx_comm *c = ctx->comm;
     if (!c) return ctx->cfg.nprocs == 1 ? FDTDX_OK : fail(FDTDX_ERR_INVALID, "no communicator: call fdtdx_comm_init or fdtdx_comm_init_local first");
+    if (c->broken) return fail(FDTDX_ERR_HIP, "an earlier RCCL call of this communicator failed: destroy it (fdtdx_comm_destroy) and set up a new one");
     if (c->epoch != c->waited) return fail(FDTDX_ERR_INVALID, "the previous exchange has not been waited for (fdtdx_comm_exchange_wait)");
     float *snd[2], *rcv[2];
     size_t cnt[2], cnt2;
@@ -285,13 +287,22 @@ extern "C" int fdtdx_comm_exchange_start(fdtdx_ctx *ctx, const char *name, void 
     if (c->mode == COMM_RCCL) {
         RcclApi *api;
         if ((rc = rccl(&api))) return rc;
-        NCCL_TRY(api, api->GroupStart());
-        for (int s = 0; s < 2; s++)
-            if (cnt[s]) {
-                NCCL_TRY(api, api->Send(snd[s], cnt[s], ncclFloat, c->peer[s], c->comm, c->xs));
-                NCCL_TRY(api, api->Recv(rcv[s], cnt[s], ncclFloat, c->peer[s], c->comm, c->xs));
-            }
-        NCCL_TRY(api, api->GroupEnd());
+        // a failure between GroupStart and GroupEnd must not leave the thread's group open (every later RCCL call of this
+        // thread, the host program's included, would queue into it and never launch): always close it, keep the first error
+        ncclResult_t first = api->GroupStart();
+        if (first == ncclSuccess) {
+            for (int s = 0; s < 2 && first == ncclSuccess; s++)
+                if (cnt[s]) {
+                    first = api->Send(snd[s], cnt[s], ncclFloat, c->peer[s], c->comm, c->xs);
+                    if (first == ncclSuccess) first = api->Recv(rcv[s], cnt[s], ncclFloat, c->peer[s], c->comm, c->xs);
+                }
+            const ncclResult_t end = api->GroupEnd();
+            if (first == ncclSuccess) first = end;
+        }
+        if (first != ncclSuccess) {
+            c->broken = true;
+            return fail(FDTDX_ERR_HIP, "RCCL send/recv group of the ghost-plane exchange: %s", api->GetErrorString(first));
+        }
     } else {
         for (int s = 0; s < 2; s++) {
             fdtdx_ctx *o = c->nb[s];
@@ -299,7 +310,9 @@ extern "C" int fdtdx_comm_exchange_start(fdtdx_ctx *ctx, const char *name, void 
             if (!o || !o->comm) return fail(FDTDX_ERR_INVALID, "the neighbouring slab is gone");
             // The copy lands in the neighbour's ghost planes of this cube, which the neighbour's sweeps queued so far may
             // still read (as the input of its previous step): wait for all it has queued.
-            if (o->comm->last_stream || o->comm->epoch) {
+            // (always: a neighbour that has not exchanged yet may have queued sweeps all the same, on the default stream too,
+            // which `last_stream == nullptr` stands for, and the exchange stream does not synchronise with that stream by itself)
+            {
                 HIP_TRY(hipSetDevice(o->device));
                 HIP_TRY(hipEventRecord(o->comm->guard[1 - s], o->comm->last_stream));
                 submit_now(o->comm->last_stream);
@@ -481,6 +494,7 @@ extern "C" int fdtdx_yee3d_slab_half_begin(fdtdx_ctx *ctx, const char *const fie
         if (ctx->cfg.nprocs != 1) return fail(FDTDX_ERR_INVALID, "no communicator: call fdtdx_comm_init or fdtdx_comm_init_local first");
         return fdtdx_yee3d_half(ctx, fields, which, coef, order, lo, hi, stream);
     }
+    if (c->broken) return fail(FDTDX_ERR_HIP, "an earlier RCCL call of this communicator failed: destroy it (fdtdx_comm_destroy) and set up a new one");
     if (c->epoch != c->waited) return fail(FDTDX_ERR_INVALID, "the previous exchange has not been waited for (fdtdx_step_end)");
     const int s = which == 0 ? 1 : 0;                                   // the side the plane travels to: up after the H half, down after the E half
     const bool snd = s ? g.ghost_hi != 0 : g.ghost_lo != 0, rcv = s ? g.ghost_lo != 0 : g.ghost_hi != 0;
@@ -501,18 +515,25 @@ extern "C" int fdtdx_yee3d_slab_half_begin(fdtdx_ctx *ctx, const char *const fie
     if (c->mode == COMM_RCCL) {
         RcclApi *api;
         if ((rc = rccl(&api))) return rc;
-        NCCL_TRY(api, api->GroupStart());
-        for (int k = 0; k < 2; k++) {
-            if (snd) NCCL_TRY(api, api->Send(cube[k] + zs * g.plane, cnt, ncclFloat, c->peer[s], c->comm, c->xs));
-            if (rcv) NCCL_TRY(api, api->Recv(cube[k] + zr * g.plane, cnt, ncclFloat, c->peer[1 - s], c->comm, c->xs));
+        ncclResult_t first = api->GroupStart();  // as in fdtdx_comm_exchange_start: the group is closed whatever happens inside it
+        if (first == ncclSuccess) {
+            for (int k = 0; k < 2 && first == ncclSuccess; k++) {
+                if (snd) first = api->Send(cube[k] + zs * g.plane, cnt, ncclFloat, c->peer[s], c->comm, c->xs);
+                if (rcv && first == ncclSuccess) first = api->Recv(cube[k] + zr * g.plane, cnt, ncclFloat, c->peer[1 - s], c->comm, c->xs);
+            }
+            const ncclResult_t end = api->GroupEnd();
+            if (first == ncclSuccess) first = end;
         }
-        NCCL_TRY(api, api->GroupEnd());
+        if (first != ncclSuccess) {
+            c->broken = true;
+            return fail(FDTDX_ERR_HIP, "RCCL send/recv group of the E/H half step: %s", api->GetErrorString(first));
+        }
     } else if (snd) {
         fdtdx_ctx *o = c->nb[s];
         if (!o || !o->comm) return fail(FDTDX_ERR_INVALID, "the neighbouring slab is gone");
         if (o->g.plane != g.plane) return fail(FDTDX_ERR_INVALID, "the neighbouring slab has another geometry");
         // the neighbour's launches queued so far may still read the ghost plane the copies land in
-        if (o->comm->last_stream || o->comm->epoch) {
+        {  // always, the default stream included (see fdtdx_comm_exchange_start)
             HIP_TRY(hipSetDevice(o->device));
             HIP_TRY(hipEventRecord(o->comm->guard[1 - s], o->comm->last_stream));
             submit_now(o->comm->last_stream);

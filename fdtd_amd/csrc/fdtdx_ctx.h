@@ -29,6 +29,7 @@ struct fdtdx_ctx {
     fdtdx_config cfg;
     fdtdx_geometry g;
     int device = 0;
+    int num_cus = 256;                 // compute units of the device (hipDeviceAttributeMultiprocessorCount), asked in fdtdx_create
     std::map<std::string, Cube> pool;  // memoryPool of stencil.h:361
     struct AddrList {
         uint64_t *ptr = nullptr;

@@ -105,10 +105,9 @@ class HipSlabBackend:
 
     def can_fuse(self, program):
         """Deepest fusion the library has a kernel for (0: none)."""
-        if program.kind == _lib.SPC13:
-            return 2  # tbs_kernel.h: two steps
-        radius = program.radius if program.kind == _lib.STAR else 1
-        return {1: 3, 2: 2}.get(radius, 0)  # tb_kernel.h: radius 1, two or three steps; tbm_kernel.h: radius 2, two steps
+        # asked of the library, so that this loop steps singly exactly where the native loops do (tb_kernel.h: radius 1, two or
+        # three steps; tbm_kernel.h: radius 2, two steps; tbs_kernel.h: 13-point, two steps, not on rows of exactly 65 quads)
+        return self.st.fusedDepth(program)
 
     def copy_cube(self, dst, src):
         self.bufs[dst].copy_(self.bufs[src])

@@ -310,6 +310,13 @@ class Stencil:
     def setOption(self, key, value):
         _lib.check(self._L.fdtdx_set_option(self._h, key.encode(), int(value)))
 
+    def fusedDepth(self, program, named_shells=False):
+        """Deepest fused launch (time steps) the library has for the program on this grid: 3, 2 or 0 (fdtdx_fused_depth)."""
+        k = self._L.fdtdx_fused_depth(self._h, ctypes.byref(program), 1 if named_shells else 0)
+        if k < 0:
+            _lib.check(-k)
+        return k
+
     def lastLaunchInfo(self):
         buf = ctypes.create_string_buffer(640)
         _lib.check(self._L.fdtdx_last_launch_info(self._h, buf, 640))

@@ -357,6 +357,12 @@ int fdtdx_yee2d_steps(int device, float *ex, float *ey, float *hz, uint64_t nx, 
  * stream, ahead of the interior sweep; 1: on a stream of the library's own, beside it -- measured slower where the
  * interior sweep fills every CU, because the boundary sweep and the exchange behind it then wait for CUs). */
 int fdtdx_set_option(fdtdx_ctx *ctx, const char *key, int64_t value);
+/* The deepest fused launch the library has for `prog` on this context's grid: 3, 2, or 0 (none; e.g. radius >= 3, or the
+ * 13-point program on rows of exactly 65 quads).  named_shells != 0: only kernels that take both shell sources by name
+ * (fdtdx_propagate_fused_shells with shell_even != in).  A query, never an error for a valid program; negative = error
+ * code negated.  Time loops written outside the library (the reference's drivers loop step by step, fdtd1.cu:68-80) ask
+ * this before they plan fused hops, so that they fall back to single steps exactly where fdtdx_sweep / fdtdx_run do. */
+int fdtdx_fused_depth(const fdtdx_ctx *ctx, const fdtdx_program *prog, int named_shells);
 /* Describes the kernels the last sweeps launched (tile shape, grid, LDS; the last fused launch if
  * any; launches issued so far), for logs and bench. */
 int fdtdx_last_launch_info(const fdtdx_ctx *ctx, char *buf, size_t len);

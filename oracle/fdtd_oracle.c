@@ -6,7 +6,7 @@
  * the "port" CPU baseline of bench.py.
  *
  * Parity status: PINNED.  Every *_golden function below is checked bit-for-bit
- * (tests/test_oracle_vs_ref.py) against the reference's own CPU golden loops
+ * (tests/test_oracle_cpu.py) against the reference's own CPU golden loops
  * compiled from /root/reference by oracle/build_ref.sh with strict IEEE flags
  * (-O2 -ffp-contract=off), and against the committed fixtures in tests/golden/
  * that were produced by those compiled loops.
