@@ -181,6 +181,8 @@ def main():
     ap.add_argument("--order", default="chain", choices=["chain", "golden"],
                     help="arithmetic order of the sweeps: chain = the device lambdas' (every + c*v one FMA), golden = the host loops' "
                          "(separate IEEE multiplies and adds: the order the reference's compiled loops pin bit for bit)")
+    ap.add_argument("--fuse-wide", action="store_true",
+                    help="one rank: run radius 3 and 4 through their two-step kernels (slower than single steps; kept for measurement)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-standing-start", dest="standing_start", action="store_false",
                     help="skip the extra 1000-step run from a standing start (one rank, sweep variants)")
@@ -409,8 +411,8 @@ def main():
         if world > 1 and a.temporal != 0:
             if kind in ("star", "jacobi7") and radius == 1:
                 ghost = 3
-            elif kind == "star" and radius == 2 and not native:
-                ghost = 4  # the radius-2 fused kernel needs a third cube on slabs: the Python loop allocates one, fdtdx_run steps singly
+            elif kind == "star" and radius == 2:
+                ghost = 4  # two steps per launch through a third cube (fdtdx_run_work / the Python loop's scratch cube)
             elif kind == "spc13":
                 ghost = 2
         Zg, Yg, Xg = ([int(v) for v in a.grid.split(",")] if a.grid else [n * world, n, n])
@@ -431,6 +433,13 @@ def main():
             be.alloc("work")
             work = "work"
         if world == 1 and kind == "jacobi7" and a.temporal == 2:
+            be.alloc("work")
+            work = "work"
+        if world == 1 and a.fuse_wide and a.temporal != 0 and kind == "star" and radius in (3, 4):
+            be.st.setOption("fuse_wide", 1)
+            be.alloc("work")
+            work = "work"
+        if native and a.temporal != 0 and kind == "star" and radius == 2:
             be.alloc("work")
             work = "work"
         run = SlabRunner(be, ghost, prog, rank, world, exchange="host" if a.rehearse_shared_gpu else "device")
@@ -465,7 +474,7 @@ def main():
                 # loop of fdtd1.cu:68-80), which fuses two steps per launch where it can
                 be.st.sweep("p0", "p1", prog, k, cs, work=work)
             elif native:
-                Stencil.run([be.st], "p0", "p1", prog, k, [cs])
+                Stencil.run([be.st], "p0", "p1", prog, k, [cs], work=work)
             else:
                 run.run("p0", "p1", k, fuse=a.temporal != 0)
 

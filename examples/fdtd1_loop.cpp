@@ -123,7 +123,7 @@ int main(int argc, char **argv)
         }
         for (auto &s : slabs) s->sync();
         std::printf("GPU time %.6lfs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count());
-        for (auto &s : slabs) s->transferCubeToCPU(host_p0.data(), "p0");
+        slabs[0]->transferCubeToCPU(host_p0.data(), "p0");  // stencil.h:610-637: gathers every slab's planes
     } else {
         std::fprintf(stderr, "usage: %s spmd <rank> <nprocs> <id file> [radius] [steps] | local <nslabs> [radius] [steps]\n", argv[0]);
         return 2;

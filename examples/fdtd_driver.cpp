@@ -31,7 +31,10 @@ static uint32_t crc32_of(const void *data, size_t n)
 template <size_t M>
 static int run(const fdtdx_program &prog, unsigned steps, bool jacobi)
 {
-    fdtdx::Stencil<float, nz, ny, nx, M> stencil;
+    using namespace fdtdx;
+    typedef uint32_t gpu_size_t;
+    typedef int32_t gpu_signed_size_t;
+    Stencil<float, nz, ny, nx, M, true, gpu_size_t, gpu_signed_size_t> stencil;  // the declaration of fdtd1.cu:17 as it stands
     stencil.mallocCube("p0", true);
     stencil.mallocCube("p1", true);
     if (jacobi) {

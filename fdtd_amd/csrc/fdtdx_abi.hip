@@ -273,7 +273,9 @@ static int copy_planes_h2d(fdtdx_ctx *ctx, float *dev, const float *host, uint64
     HIP_TRY(hipMemcpy2D(dev, g.pitch_x * sizeof(float), host, X * sizeof(float), X * sizeof(float), nplanes * Y, hipMemcpyHostToDevice));
     return FDTDX_OK;
 }
-static int copy_planes_d2h(fdtdx_ctx *ctx, float *host, const float *dev, uint64_t nplanes)
+int fdtdx_copy_planes_d2h(fdtdx_ctx *ctx, float *host, const float *dev, uint64_t nplanes);
+static int copy_planes_d2h(fdtdx_ctx *ctx, float *host, const float *dev, uint64_t nplanes) { return fdtdx_copy_planes_d2h(ctx, host, dev, nplanes); }
+int fdtdx_copy_planes_d2h(fdtdx_ctx *ctx, float *host, const float *dev, uint64_t nplanes)
 {
     USE_DEVICE(ctx);
     // stencil.h:615: the reference synchronises the device before it copies a cube back; sweeps queued on
@@ -597,6 +599,10 @@ static const TbVariantInfo *pick_tb(const fdtdx_ctx *ctx, const fdtdx_program *p
     // row whose first and last quad (both with a shell cell) are 64 apart (rows of exactly 65 quads) does not fit; such
     // grids run single steps.
     const bool shells_fit = prog->kind != FDTDX_SPC13 || (ctx->cfg.X + 3) / 4 != 65;
+    // The two-step kernels of radius 3 and 4 exist for measurement: a tile of 24 rows x 64 quads stores 12 (radius 3) or 8
+    // (radius 4) rows and 60 quads, so they compute 2-3 times what they store and run slower than single steps.  They are
+    // only picked when the "fuse_wide" option asks for them.
+    if (radius >= 3 && !ctx->opt_fuse_wide) return nullptr;
     const TbVariantInfo *best = nullptr;
     int idx = 0;
     for (int i = 0; i < num_tb_variants(); i++) {
@@ -650,20 +656,21 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
     const int owned = v->nw * v->ry - 2 * reach;
     p.gy = (p.ny - 2 * v->radius + owned - 1) / owned;
     const int nq = (p.nx + 3) / 4, tq = 64 * v->rx;
-    // Rows wider than one tile are cut into x tiles that overlap by one quad on each side (a tile stores
-    // tq-2 quads).  Where the last tile has at most 62 quads left to store and the shape exists at half
+    // Rows wider than one tile are cut into x tiles that overlap by `ovq` quads on each side (a tile stores
+    // tq - 2 ovq quads; ovq = 1 for every fused kernel of radius 1 and 2).  Where the last tile has at most 62 quads left to store and the shape exists at half
     // the width, that tile is launched separately with the half-width kernel: rows of 1024 cells then
     // cost 2.5 tile widths instead of 3.
     const TbVariantInfo *narrow = nullptr;
     int gx_full = 1;
+    const int ovq = (reach + 3) / 4;  // quads an x tile shares with its neighbour on each side: what kt steps reach into
     if (nq <= tq) {
         p.gx = 1, p.qstep = tq, p.qbase = 0, p.xt = 0;
     } else {
-        p.qstep = tq - 2, p.qbase = -1, p.xt = 1;
+        p.qstep = tq - 2 * ovq, p.qbase = -ovq, p.xt = 1;
         gx_full = (nq + p.qstep - 1) / p.qstep;
         p.gx = gx_full;
         const int rem = nq - (gx_full - 1) * p.qstep;
-        if (rem <= 62 && v->rx == 2 && ctx->opt_tb_variant < 0)
+        if (rem <= 64 - 2 * ovq && v->rx == 2 && ctx->opt_tb_variant < 0)
             for (int i = 0; i < num_tb_variants(); i++) {
                 const TbVariantInfo *c = tb_variant(i);
                 if (c->order == v->order && c->kt == v->kt && c->radius == v->radius && c->nw == v->nw && c->ry == v->ry && c->rx == 1) narrow = c;
@@ -703,7 +710,7 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
     int rc;
     if (narrow) {  // first the half-width tail (its grid is reported last otherwise), then the full-width tiles
         TbParams t = p;
-        t.gx = 1, t.qbase = -1 + (gx_full - 1) * p.qstep;
+        t.gx = 1, t.qbase = -ovq + (gx_full - 1) * p.qstep;
         if ((rc = launch_part(narrow, t))) return rc;
     }
     if ((rc = launch_part(v, p))) return rc;
@@ -1001,6 +1008,15 @@ extern "C" int fdtdx_addr_size(fdtdx_ctx *ctx, const char *name, uint64_t *count
     if (!ctx || !name || !count) return fail(FDTDX_ERR_INVALID, "null argument");
     auto it = ctx->addr.find(name);
     *count = (it == ctx->addr.end()) ? 0 : it->second.count;  // getAddrSize (stencil.h:500-504): 0 for an unknown name
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_get_addr(fdtdx_ctx *ctx, const char *name, uint64_t **device_ptr)
+{
+    if (!ctx || !name || !device_ptr) return fail(FDTDX_ERR_INVALID, "null argument");
+    auto it = ctx->addr.find(name);
+    if (it == ctx->addr.end()) return fail(FDTDX_ERR_NOTFOUND, "no address list named '%s'", name);
+    *device_ptr = it->second.ptr;  // get<size_t>(name) of stencil.h:479-484: borrowed
     return FDTDX_OK;
 }
 
@@ -1408,6 +1424,10 @@ extern "C" int fdtdx_set_option(fdtdx_ctx *ctx, const char *key, int64_t value)
         ctx->opt_tb_zchunks = value;
     else if (!strcmp(key, "boundary_stream"))
         ctx->opt_boundary_stream = value != 0;
+    else if (!strcmp(key, "exchange_priority"))
+        ctx->opt_exchange_priority = value != 0;
+    else if (!strcmp(key, "fuse_wide"))
+        ctx->opt_fuse_wide = value != 0;
     else if (!strcmp(key, "reserve_cus"))
         ctx->opt_reserve_cus = std::max<int64_t>(0, std::min<int64_t>(value, 255));
     else

@@ -24,6 +24,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 
@@ -38,6 +39,7 @@ struct RcclApi {
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 
@@ -65,6 +67,7 @@ int rccl(RcclApi **out)
         SYM(GroupEnd, "ncclGroupEnd")
         SYM(Send, "ncclSend")
         SYM(Recv, "ncclRecv")
+        SYM(Broadcast, "ncclBroadcast")
         SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
         api.handle = h;
@@ -100,6 +103,7 @@ struct fdtdx_comm {
     // RCCL
     ncclComm_t comm = nullptr;
     int peer[2] = {-1, -1};         // communicator ranks of the neighbours below / above
+    int comm_rank = -1, comm_size = 0;
     // local
     fdtdx_ctx *nb[2] = {nullptr, nullptr};
 };
@@ -120,7 +124,13 @@ static int comm_streams(fdtdx_ctx *ctx, fdtdx_comm *c)
     // An ordinary stream.  (A high-priority one, meant to get the exchange's few workgroups ahead of an interior sweep
     // that fills every CU, left the device waiting for ever once a process had created a handful of streams: the second
     // two-slab run with a stream per slab never finished.  Room for the exchange is made with the "reserve_cus" option.)
-    HIP_TRY(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
+    if (ctx->opt_exchange_priority) {  // "exchange_priority" option: the exchange stream at the device's highest priority
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&c->xs, hipStreamNonBlocking, greatest));
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
+    }
     HIP_TRY(hipStreamCreateWithFlags(&c->bs, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
@@ -154,6 +164,34 @@ void fdtdx_comm_release(fdtdx_ctx *ctx)
         if (c->nb[s] && c->nb[s]->comm && c->nb[s]->comm->nb[1 - s] == ctx) c->nb[s]->comm->nb[1 - s] = nullptr;
     delete c;
     ctx->comm = nullptr;
+}
+
+// What of this slab's exchange machinery has completed on the device, as text: for finding the wait that never fires when
+// a multi-stream run stops making progress.  Queries only; nothing is queued or waited for.
+extern "C" int fdtdx_comm_state(fdtdx_ctx *ctx, char *buf, size_t len)
+{
+    if (!ctx || !buf || !len) return fail(FDTDX_ERR_INVALID, "null argument");
+    fdtdx_comm *c = ctx->comm;
+    if (!c) {
+        snprintf(buf, len, "no communicator");
+        return FDTDX_OK;
+    }
+    USE_DEVICE(ctx);
+    auto ev = [](hipEvent_t e) {
+        if (!e) return "none";
+        const hipError_t r = hipEventQuery(e);
+        if (r != hipSuccess) (void)hipGetLastError();
+        return r == hipSuccess ? "fired" : r == hipErrorNotReady ? "PENDING" : "error";
+    };
+    auto st = [](hipStream_t s) {
+        const hipError_t r = hipStreamQuery(s);
+        if (r != hipSuccess) (void)hipGetLastError();
+        return r == hipSuccess ? "idle" : r == hipErrorNotReady ? "BUSY" : "error";
+    };
+    snprintf(buf, len, "rank %u mode=%s epoch=%llu waited=%llu | events: fork=%s ready=%s done=%s guard_lo=%s guard_hi=%s | streams: exchange=%s boundary=%s caller(last)=%s",
+             ctx->cfg.rank, c->mode == COMM_RCCL ? "rccl" : "local", (unsigned long long)c->epoch, (unsigned long long)c->waited, ev(c->fork), ev(c->ready),
+             ev(c->done), ev(c->guard[0]), ev(c->guard[1]), st(c->xs), st(c->bs), st(c->last_stream));
+    return FDTDX_OK;
 }
 
 extern "C" int fdtdx_comm_destroy(fdtdx_ctx *ctx)
@@ -191,6 +229,7 @@ extern "C" int fdtdx_comm_init_ranks(fdtdx_ctx *ctx, const fdtdx_comm_id *id, in
     if (!c) return fail(FDTDX_ERR_NOMEM, "out of host memory");
     c->mode = COMM_RCCL;
     c->peer[0] = g.ghost_lo ? peer_lo : -1, c->peer[1] = g.ghost_hi ? peer_hi : -1;
+    c->comm_rank = comm_rank, c->comm_size = comm_size;
     ctx->comm = c;
     if ((rc = comm_streams(ctx, c))) {
         fdtdx_comm_release(ctx);
@@ -399,6 +438,76 @@ extern "C" int fdtdx_comm_barrier(fdtdx_ctx *ctx)
     return FDTDX_OK;
 }
 
+// transferCubeToCPU's gather (stencil.h:623-636: Recv of every rank's slab on rank 0, Send elsewhere, then a chunked
+// Bcast): every rank ends with the whole unpadded [Z][Y][X] grid in `host`.  Here every rank's owned planes travel once,
+// device to device (one ncclBroadcast per slab into a staging buffer, no host-side Send/Recv/Bcast), and each rank unpads
+// what arrives straight into its place in `host`.  Slabs of one process: the chain of slabs is walked and each slab's
+// planes are copied out by its own device.  One rank: the plain download.
+extern "C" int fdtdx_gather_cube(fdtdx_ctx *ctx, float *host, const char *name)
+{
+    if (!ctx || !host || !name) return fail(FDTDX_ERR_INVALID, "null argument");
+    const uint64_t plane_host = (uint64_t)ctx->cfg.Y * ctx->cfg.X;
+    auto own_part = [&](fdtdx_ctx *o) -> int {
+        float *d;
+        int rc = fdtdx_find_cube(o, name, &d);
+        if (rc) return rc;
+        const fdtdx_geometry &g = o->g;
+        return fdtdx_copy_planes_d2h(o, host + g.owned_begin * plane_host, d + g.ghost_lo * g.plane, g.owned_planes);
+    };
+    fdtdx_comm *c = ctx->comm;
+    if (!c) return ctx->cfg.nprocs == 1 ? own_part(ctx) : fail(FDTDX_ERR_INVALID, "no communicator: call fdtdx_comm_init or fdtdx_comm_init_local first");
+    if (c->mode == COMM_LOCAL) {
+        int rc = own_part(ctx);
+        for (int s = 0; s < 2 && !rc; s++)
+            for (fdtdx_ctx *o = c->nb[s]; o && !rc; o = o->comm ? o->comm->nb[s] : nullptr) rc = own_part(o);
+        if (hipSetDevice(ctx->device) != hipSuccess) (void)hipGetLastError();
+        return rc;
+    }
+    // RCCL: the communicator must be the one fdtdx_comm_init makes (communicator rank == slab rank)
+    const int n = (int)ctx->cfg.nprocs;
+    if (c->comm_size != n || c->comm_rank != (int)ctx->cfg.rank)
+        return fail(FDTDX_ERR_UNSUPPORTED, "fdtdx_gather_cube needs a communicator whose ranks are the slab ranks (fdtdx_comm_init)");
+    if (c->broken) return fail(FDTDX_ERR_HIP, "an earlier RCCL call of this communicator failed");
+    RcclApi *api;
+    int rc = rccl(&api);
+    if (rc) return rc;
+    float *mine;
+    if ((rc = fdtdx_find_cube(ctx, name, &mine))) return rc;
+    USE_DEVICE(ctx);
+    HIP_TRY(hipDeviceSynchronize());  // stencil.h:615: everything queued has finished before the cube is read
+    uint64_t most = 0;
+    for (int r = 0; r < n; r++) {
+        fdtdx_config cf = ctx->cfg;
+        cf.rank = (uint32_t)r;
+        fdtdx_geometry gr;
+        if ((rc = fdtdx_decompose(&cf, &gr))) return rc;
+        most = std::max<uint64_t>(most, gr.owned_planes);
+    }
+    float *stage = nullptr;
+    HIP_TRY(hipMalloc((void **)&stage, most * ctx->g.plane * sizeof(float)));
+    for (int r = 0; r < n && !rc; r++) {
+        fdtdx_config cf = ctx->cfg;
+        cf.rank = (uint32_t)r;
+        fdtdx_geometry gr;
+        if ((rc = fdtdx_decompose(&cf, &gr))) break;
+        const size_t cnt = (size_t)(gr.owned_planes * gr.plane);
+        const float *src = (r == c->comm_rank) ? mine + ctx->g.ghost_lo * ctx->g.plane : stage;
+        const ncclResult_t e = api->Broadcast(src, stage, cnt, ncclFloat, r, c->comm, c->xs);
+        if (e != ncclSuccess) {
+            c->broken = true;
+            rc = fail(FDTDX_ERR_HIP, "ncclBroadcast of slab %d: %s", r, api->GetErrorString(e));
+            break;
+        }
+        if (hipStreamSynchronize(c->xs) != hipSuccess) {
+            rc = fail(FDTDX_ERR_HIP, "hipStreamSynchronize after the broadcast of slab %d failed", r);
+            break;
+        }
+        rc = fdtdx_copy_planes_d2h(ctx, host + gr.owned_begin * plane_host, stage, gr.owned_planes);
+    }
+    if (hipFree(stage) != hipSuccess && !rc) rc = fail(FDTDX_ERR_HIP, "hipFree(staging) failed");
+    return rc;
+}
+
 // ---- the time step of a multi-rank driver (fdtd1.cu:70-78) ------------------------------------------------------
 static void update_range(const fdtdx_ctx *ctx, uint64_t r, uint64_t *lo, uint64_t *hi)
 {
@@ -565,6 +674,15 @@ extern "C" int fdtdx_yee3d_slab_half_begin(fdtdx_ctx *ctx, const char *const fie
 extern "C" int fdtdx_run(fdtdx_ctx *const *ctxs, int n, const char *a, const char *b, const fdtdx_program *prog, uint32_t steps,
                          void *const *streams)
 {
+    return fdtdx_run_work(ctxs, n, a, b, nullptr, prog, steps, streams);
+}
+
+// `work` (may be null): a third cube of every slab's pool for the two-step loops that hop through one (the radius-2 star:
+// its fused kernel takes the even levels' shell from its input cube, so the loop runs b -> work -> b with `a` lending its
+// shell to the odd levels, as fdtdx_sweep_work does on one rank).  Nothing is allocated here.
+extern "C" int fdtdx_run_work(fdtdx_ctx *const *ctxs, int n, const char *a, const char *b, const char *work, const fdtdx_program *prog,
+                              uint32_t steps, void *const *streams)
+{
     if (!ctxs || n < 1 || !a || !b) return fail(FDTDX_ERR_INVALID, "null argument");
     uint64_t r;
     int rc = program_radius(prog, &r);
@@ -584,9 +702,17 @@ extern "C" int fdtdx_run(fdtdx_ctx *const *ctxs, int n, const char *a, const cha
             if (r1 && want != 2 && (!multi || G >= 3 * r) && fdtdx_has_fused(ctxs[0], prog, 3, false))
                 kt = 3;  // straight between the two cubes
             else if (want != 3 && (!multi || G >= 2 * r) && fdtdx_has_fused(ctxs[0], prog, 2, true))
-                kt = 2;  // in place via the named shell sources (13-point, radius-2 star)
+                kt = 2;  // in place via the named shell sources (13-point)
+            else if (want != 3 && work && (!multi || G >= 2 * r) && fdtdx_has_fused(ctxs[0], prog, 2, false))
+                kt = -2;  // two steps per launch through the third cube (radius-2 star)
         }
     }
+    if (kt == -2)
+        for (int i = 0; i < n; i++) {
+            float *pa, *pb, *pw;
+            if ((rc = fdtdx_find_cube(ctxs[i], a, &pa)) || (rc = fdtdx_find_cube(ctxs[i], b, &pb)) || (rc = fdtdx_find_cube(ctxs[i], work, &pw))) return rc;
+            if (pw == pa || pw == pb) return fail(FDTDX_ERR_INVALID, "the work cube must be a third cube");
+        }
     auto each = [&](auto &&f) {
         for (int i = 0; i < n; i++)
             if (int e = f(i)) return e;
@@ -606,6 +732,33 @@ extern "C" int fdtdx_run(fdtdx_ctx *const *ctxs, int n, const char *a, const cha
             if ((rc = each([&](int i) { return fdtdx_hop_begin(ctxs[i], out, in, b, a, prog, 2, stream_of(i)); }))) return rc;
             if ((rc = each([&](int i) { return fdtdx_step_end(ctxs[i], stream_of(i)); }))) return rc;
             done += 2;
+        }
+    } else if (kt == -2) {
+        const uint32_t pairs = (steps % 2 == 0) ? steps / 2 - 1 : ((steps - 1) / 2) & ~1u;
+        if (pairs > 0) {
+            // work starts as a copy of b (ghost planes and shell included): it carries b's shell through the loop
+            if ((rc = each([&](int i) {
+                    float *pb, *pw;
+                    int e;
+                    if ((e = fdtdx_find_cube(ctxs[i], b, &pb)) || (e = fdtdx_find_cube(ctxs[i], work, &pw))) return e;
+                    if (hipSetDevice(ctxs[i]->device) != hipSuccess) return fail(FDTDX_ERR_HIP, "hipSetDevice(%d) failed", ctxs[i]->device);
+                    if (hipMemcpyAsync(pw, pb, ctxs[i]->g.cube_elems * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream_of(i)) != hipSuccess)
+                        return fail(FDTDX_ERR_HIP, "copy of cube '%s' into the work cube failed", b);
+                    return 0;
+                })))
+                return rc;
+            const char *cur = b, *oth = work;
+            for (uint32_t k = 0; k < pairs; k++) {
+                if ((rc = each([&](int i) { return fdtdx_hop_begin(ctxs[i], oth, cur, cur, a, prog, 2, stream_of(i)); }))) return rc;
+                if ((rc = each([&](int i) { return fdtdx_step_end(ctxs[i], stream_of(i)); }))) return rc;
+                std::swap(cur, oth);
+            }
+            done = 2 * pairs;
+            if (cur != b) {  // even step count, odd number of pairs: the newest even level sits in the work cube; step from there
+                if ((rc = each([&](int i) { return fdtdx_step_begin(ctxs[i], a, cur, prog, stream_of(i)); }))) return rc;
+                if ((rc = each([&](int i) { return fdtdx_step_end(ctxs[i], stream_of(i)); }))) return rc;
+                done++;
+            }
         }
     }
     // single steps: where there are more than a few, the sweeps take the shell components of partly stored quads from strips

@@ -42,6 +42,8 @@ struct fdtdx_ctx {
     int64_t opt_tb_variant = -1;       // shape of the fused kernel, -1 = auto
     int64_t opt_tb_zchunks = 0;
     int64_t opt_boundary_stream = 0;   // 1: a multi-rank step's boundary-plane sweep runs on a stream of its own, beside the interior sweep
+    int64_t opt_exchange_priority = 0; // 1: the exchange stream is created at the device's highest stream priority (read when the communicator is set up)
+    int64_t opt_fuse_wide = 0;         // 1: time loops may use the two-step kernels of radius 3 and 4 (slower than single steps: kept for measurement)
     int64_t opt_reserve_cus = 0;       // CUs a sweep launch leaves without a workgroup (room for the exchange's kernels)
     float *tb_scratch = nullptr;       // third cube of the fused time loop (owned)
     float *shell_strip[2] = {nullptr, nullptr};  // time loops: the shell components of the quads that straddle the x shell, per cube of the loop (owned)
@@ -73,3 +75,5 @@ bool fdtdx_strips_bind(fdtdx_ctx *ctx, const float *a, const float *b, int r, vo
 void fdtdx_strips_release(fdtdx_ctx *ctx);
 bool fdtdx_has_fused(const fdtdx_ctx *ctx, const fdtdx_program *prog, int kt, bool shells);
 void fdtdx_comm_release(fdtdx_ctx *ctx);  // called by fdtdx_destroy
+// `nplanes` padded planes at device address `dev` into unpadded [nplanes][Y][X] host memory (the device is drained first)
+int fdtdx_copy_planes_d2h(fdtdx_ctx *ctx, float *host, const float *dev, uint64_t nplanes);

@@ -125,7 +125,10 @@ __global__ __launch_bounds__(NW * 64) void tb_rm_kernel(const TbParams p)
             const int lq = lane + 64 * i;
             const int qx = tq0 + lq;
             const int x0 = 4 * qx;
-            const bool xown = !xtiled || (lq >= 1 && lq < 64 * RX - 1);
+            // x tiles overlap by the quads two levels reach into (one for radius 2, two for radius 3 and 4): a tile's
+            // outermost OVQ quads on either side are a neighbouring tile's to store
+            constexpr int OVQ = (KT * M + 3) / 4;
+            const bool xown = !xtiled || (lq >= OVQ && lq < 64 * RX - OVQ);
             unsigned m = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++)

@@ -111,6 +111,7 @@ SYMBOLS = {
     "fdtdx_comm_init_local": (ctypes.c_int, [_P(_vp), ctypes.c_int]),
     "fdtdx_comm_destroy": (ctypes.c_int, [_vp]),
     "fdtdx_comm_barrier": (ctypes.c_int, [_vp]),
+    "fdtdx_comm_state": (ctypes.c_int, [_vp, _c, ctypes.c_size_t]),
     "fdtdx_comm_boundary_done": (ctypes.c_int, [_vp, _vp]),
     "fdtdx_comm_exchange_start": (ctypes.c_int, [_vp, _c, _vp]),
     "fdtdx_comm_exchange_wait": (ctypes.c_int, [_vp, _vp]),
@@ -120,6 +121,9 @@ SYMBOLS = {
     "fdtdx_step_end": (ctypes.c_int, [_vp, _vp]),
     "fdtdx_yee3d_slab_half_begin": (ctypes.c_int, [_vp, _P(_c), ctypes.c_int, ctypes.c_float, ctypes.c_uint32, _vp]),
     "fdtdx_run": (ctypes.c_int, [_P(_vp), ctypes.c_int, _c, _c, _P(Program), ctypes.c_uint32, _P(_vp)]),
+    "fdtdx_run_work": (ctypes.c_int, [_P(_vp), ctypes.c_int, _c, _c, _c, _P(Program), ctypes.c_uint32, _P(_vp)]),
+    "fdtdx_gather_cube": (ctypes.c_int, [_vp, _vp, _c]),
+    "fdtdx_get_addr": (ctypes.c_int, [_vp, _c, _P(_vp)]),
     "fdtdx_fused_depth": (ctypes.c_int, [_vp, _P(Program), ctypes.c_int]),
     "fdtdx_set_option": (ctypes.c_int, [_vp, _c, ctypes.c_int64]),
     "fdtdx_last_launch_info": (ctypes.c_int, [_vp, _c, ctypes.c_size_t]),

@@ -83,6 +83,17 @@ class Stencil:
         assert cpu.dtype == np.float32 and cpu.flags["C_CONTIGUOUS"] and cpu.shape == (self.Z, self.Y, self.X)
         _lib.check(self._L.fdtdx_transfer_cube_to_cpu(self._h, cpu.ctypes.data_as(ctypes.c_void_p), name.encode()))
 
+    def gatherCube(self, cpu, name):
+        """transferCubeToCPU with its cross-rank gather (stencil.h:610-637): every rank ends with the whole grid."""
+        assert cpu.dtype == np.float32 and cpu.flags["C_CONTIGUOUS"] and cpu.shape == (self.Z, self.Y, self.X)
+        _lib.check(self._L.fdtdx_gather_cube(self._h, cpu.ctypes.data_as(ctypes.c_void_p), name.encode()))
+
+    def getAddr(self, name):
+        """Device address of an address list (get<size_t>(name), stencil.h:479-484)."""
+        p = ctypes.c_void_p()
+        _lib.check(self._L.fdtdx_get_addr(self._h, name.encode(), ctypes.byref(p)))
+        return p.value
+
     def uploadLocal(self, name, local):
         local = np.ascontiguousarray(local, np.float32)
         assert local.shape == (self.geometry.local_planes, self.Y, self.X), local.shape
@@ -271,6 +282,12 @@ class Stencil:
         arr = (ctypes.c_void_p * len(stencils))(*[s._h for s in stencils])
         _lib.check(_lib.load().fdtdx_comm_init_local(arr, len(stencils)))
 
+    def commState(self):
+        """Which exchange events have fired / which streams are idle, as text (fdtdx_comm_state; queries only)."""
+        buf = ctypes.create_string_buffer(640)
+        _lib.check(self._L.fdtdx_comm_state(self._h, buf, 640))
+        return buf.value.decode()
+
     def barrier(self):
         """stencil.h:435-438."""
         _lib.check(self._L.fdtdx_comm_barrier(self._h))
@@ -299,12 +316,13 @@ class Stencil:
         _lib.check(self._L.fdtdx_step_end(self._h, ctypes.c_void_p(stream or 0)))
 
     @staticmethod
-    def run(stencils, a, b, program, steps, streams=None):
-        """The drivers' whole loop (fdtd1.cu:68-80) on the slabs this process owns (one with RCCL, all in local mode)."""
+    def run(stencils, a, b, program, steps, streams=None, work=None):
+        """The drivers' whole loop (fdtd1.cu:68-80) on the slabs this process owns (one with RCCL, all in local mode).
+        work: name of a third cube in every slab's pool, for the two-step loops that hop through one (radius-2 star)."""
         n = len(stencils)
         arr = (ctypes.c_void_p * n)(*[s._h for s in stencils])
         st = (ctypes.c_void_p * n)(*[ctypes.c_void_p(x or 0) for x in streams]) if streams else None
-        _lib.check(_lib.load().fdtdx_run(arr, n, a.encode(), b.encode(), ctypes.byref(program), steps, st))
+        _lib.check(_lib.load().fdtdx_run_work(arr, n, a.encode(), b.encode(), work.encode() if work else None, ctypes.byref(program), steps, st))
 
     # -- tuning ------------------------------------------------------------------------------
     def setOption(self, key, value):

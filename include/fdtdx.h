@@ -121,6 +121,11 @@ int fdtdx_transfer_cube_to_gpu(fdtdx_ctx *ctx, const char *name, const float *ho
  * into their place in the unpadded global grid `host`.  The cross-rank gather/broadcast of
  * stencil.h:623-636 is done by the caller's communicator (fdtd_amd.slab.gather_cube). */
 int fdtdx_transfer_cube_to_cpu(fdtdx_ctx *ctx, float *host, const char *name);
+/* Stencil::transferCubeToCPU whole (stencil.h:610-637, the Recv/Send/Bcast of :623-636 included): every rank ends with
+ * the WHOLE unpadded [Z][Y][X] grid in `host`.  With an RCCL communicator made by fdtdx_comm_init (every rank must
+ * call): each slab's owned planes are broadcast device to device and unpadded on arrival.  Slabs of one process
+ * (fdtdx_comm_init_local): one call on any slab fills the whole grid.  One rank: same as fdtdx_transfer_cube_to_cpu. */
+int fdtdx_gather_cube(fdtdx_ctx *ctx, float *host, const char *name);
 /* Same transfers for a caller that holds only its own planes: `host_local` is
  * [local_planes][Y][X] (upload) / [owned_planes][Y][X] (download). */
 int fdtdx_upload_local(fdtdx_ctx *ctx, const char *name, const float *host_local);
@@ -229,6 +234,9 @@ int fdtdx_comm_init_local(fdtdx_ctx *const *ctxs, int n);
 int fdtdx_comm_destroy(fdtdx_ctx *ctx); /* fdtdx_destroy does it too */
 /* Stencil::barrier (stencil.h:435-438): this slab's queued work has finished and every slab of the chain has arrived. */
 int fdtdx_comm_barrier(fdtdx_ctx *ctx);
+/* Diagnostic: one line of text saying which of this slab's exchange events have fired and which of its streams are idle
+ * (queries only).  For finding the wait that never completes when a run with several streams stops making progress. */
+int fdtdx_comm_state(fdtdx_ctx *ctx, char *buf, size_t len);
 /* Start the exchange of cube `name` behind everything queued on `stream` so far (or behind the point last marked with
  * fdtdx_comm_boundary_done, for drivers that queue the interior sweep before they call the exchange, as fdtd1.cu:70-75
  * does) / make work queued on `stream` after the call see the received ghost planes.  cube_halo = start + wait. */
@@ -250,6 +258,11 @@ int fdtdx_step_end(fdtdx_ctx *ctx, void *stream);
  * (M >= 3, M >= 2); on return a / b hold what the reference's cubes hold after `steps` steps. */
 int fdtdx_run(fdtdx_ctx *const *ctxs, int n, const char *a, const char *b, const fdtdx_program *prog, uint32_t steps,
               void *const *streams);
+/* The same loop with a third cube named (`work`, in every slab's pool; NULL = fdtdx_run): the radius-2 star then fuses two
+ * steps per launch as well (ghost depth M >= 4), hopping b -> work -> b as fdtdx_sweep_work does on one rank.  Nothing is
+ * allocated inside; the contents of `work` are overwritten. */
+int fdtdx_run_work(fdtdx_ctx *const *ctxs, int n, const char *a, const char *b, const char *work, const fdtdx_program *prog,
+                   uint32_t steps, void *const *streams);
 
 /* ---- the composite pipeline of main.cu (the only caller of inject / filt / address lists) ------------ */
 
@@ -278,6 +291,8 @@ int fdtdx_propagate_composite(fdtdx_ctx *ctx, const char *out, const char *in, c
 int fdtdx_malloc_addr(fdtdx_ctx *ctx, const char *name, uint64_t capacity);
 int fdtdx_transfer_addr_to_gpu(fdtdx_ctx *ctx, const char *name, const uint64_t *global_addr, uint64_t n);
 int fdtdx_addr_size(fdtdx_ctx *ctx, const char *name, uint64_t *count);
+/* get<size_t>(name) (stencil.h:479-484) for an address list: the device array of re-based local addresses (borrowed). */
+int fdtdx_get_addr(fdtdx_ctx *ctx, const char *name, uint64_t **device_ptr);
 
 /* inject (stencil.h:810-815) with the functor of main.cu:120-123: cube[addr[i]] += add (atomic) for the
  * listed addresses that lie in local planes [z_lo, z_hi) (the reference keeps separate lists for its
@@ -351,7 +366,10 @@ int fdtdx_yee2d_steps(int device, float *ex, float *ey, float *hz, uint64_t nx, 
 /* Kernel-selection knobs, for tuning and tests: "zchunks" (z-chunks per sweep launch, 0 = auto),
  * "variant" (tile-shape index, -1 = auto), "temporal" (time steps fdtdx_sweep fuses per launch where
  * a fused kernel exists: 1 = as many as there is a kernel for, 2, 3, or 0 = one launch per step),
- * "tb_variant" / "tb_zchunks" (shape and z-chunks of the fused kernel), "reserve_cus" (CUs a sweep launch leaves
+ * "exchange_priority" (1: the exchange stream of a communicator set up afterwards is created at the device's highest stream
+ * priority; 0, default: an ordinary stream), "tb_variant" / "tb_zchunks" (shape and z-chunks of the fused kernel), "fuse_wide" (1: time loops and
+ * fdtdx_propagate_fused_* may use the two-step kernels of star radius 3 and 4, which exist for measurement and run slower than
+ * single steps; 0, default: those radii run one step per launch), "reserve_cus" (CUs a sweep launch leaves
  * without a workgroup when it sizes its grid: room for the exchange's kernels beside an interior sweep),
  * "boundary_stream" (0, default: fdtdx_step_begin / fdtdx_hop_begin queue the boundary-plane sweep in the caller's
  * stream, ahead of the interior sweep; 1: on a stream of the library's own, beside it -- measured slower where the

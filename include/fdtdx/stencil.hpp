@@ -60,9 +60,15 @@ inline fdtdx_composite main_composite(unsigned order = FDTDX_ORDER_CHAIN)
     return c;
 }
 
-template <typename DataType, size_t ZSize, size_t YSize, size_t XSize, size_t M, bool FDTD = true>
+// The reference's full template header (stencil.h:357), so that a driver's declaration compiles as it stands (fdtd1.cu:17:
+// Stencil<float, nz, ny, nx, 1, true, gpu_size_t, gpu_signed_size_t>).  The index types matter to the functor kernels of
+// stencil_functor.hpp only; BLOCK_SIZE, THREADS, PADDINGL and PADDINGR are accepted and ignored: tile shapes are chosen per
+// radius on the device and the row pitch is fixed by the library (fdtdx_geometry.pitch_x; no left padding).
+template <typename DataType, size_t ZSize, size_t YSize, size_t XSize, size_t M, bool FDTD = true, typename gpu_size_t = uint32_t,
+          typename gpu_signed_size_t = int32_t, size_t BLOCK_SIZE = 32, size_t THREADS = 256, size_t PADDINGL = 0, size_t PADDINGR = 0>
 class Stencil {
     static_assert(std::is_same<DataType, float>::value, "the sweep kernels are fp32 (every shipped driver uses float)");
+    static_assert(M <= 8 && ZSize >= 2 * M + 1, "stencil.h:387: M <= 8 and Z >= 2M+1");
     fdtdx_ctx *ctx_ = nullptr;
     fdtdx_geometry g_{};
     std::string boundary_of_;                // the cube whose boundary planes have been swept ahead of the interior
@@ -119,9 +125,19 @@ public:
         FDTDX_ASSERT(fdtdx_get_cube(ctx_, name.c_str(), &p));
         return p;
     }
-    // stencil.h:596-637 (the cross-rank gather of :623-636 is the launcher's job)
+    // the first / last 3M planes of the local cube: what getCubeHalo{Top,Buttom}Backup alias for a cube without side buffers
+    // in the reference (stencil.h:584-594).  Here no cube has side buffers (ghost planes live in the cube).
+    DataType *getCubeHaloTopBackup(const std::string &name) { return getCube(name); }
+    DataType *getCubeHaloButtomBackup(const std::string &name)
+    {
+        const uint64_t planes = g_.local_planes > 3 * M ? g_.local_planes - 3 * M : 0;
+        return getCube(name) + planes * g_.plane;
+    }
+    // stencil.h:596-637.  transferCubeToCPU: every rank ends with the whole grid (the Recv/Send/Bcast of :623-636 happen
+    // inside the library, device to device); transferOwnedToCPU writes only this rank's planes into their place.
     void transferCubeToGPU(const std::string &name, DataType *cpu) { FDTDX_ASSERT(fdtdx_transfer_cube_to_gpu(ctx_, name.c_str(), cpu)); }
-    void transferCubeToCPU(DataType *cpu, const std::string &name) { FDTDX_ASSERT(fdtdx_transfer_cube_to_cpu(ctx_, cpu, name.c_str())); }
+    void transferCubeToCPU(DataType *cpu, const std::string &name) { FDTDX_ASSERT(fdtdx_gather_cube(ctx_, cpu, name.c_str())); }
+    void transferOwnedToCPU(DataType *cpu, const std::string &name) { FDTDX_ASSERT(fdtdx_transfer_cube_to_cpu(ctx_, cpu, name.c_str())); }
 
     // stencil.h:684-768.  `spill` only chose launch bounds in the reference; ignored.  Where the planes next to the
     // neighbours have already been swept into this cube (propagateHalo{Top,Buttom}Backup since the last exchange), only
@@ -226,6 +242,16 @@ public:
         FDTDX_ASSERT(fdtdx_addr_size(ctx_, name.c_str(), &n));
         return (size_t)n;
     }
+    uint64_t *getAddr(const std::string &name)  // get<size_t>(name) of an address list (stencil.h:479-484)
+    {
+        uint64_t *p = nullptr;
+        FDTDX_ASSERT(fdtdx_get_addr(ctx_, name.c_str(), &p));
+        return p;
+    }
+    // The reference keeps two more lists per address buffer, for replaying inject on its side buffers (stencil.h:486-516,
+    // 534-535).  There are no side buffers here, so these lists are empty: an inject over them touches nothing.
+    size_t getAddrHaloTopSize(const std::string &) { return 0; }
+    size_t getAddrHaloButtomSize(const std::string &) { return 0; }
     void inject(const std::string &cube, const std::string &addr, float add, void *stream = nullptr)
     {
         FDTDX_ASSERT(fdtdx_inject(ctx_, cube.c_str(), addr.c_str(), add, g_.ghost_lo, g_.ghost_lo + g_.owned_planes, stream));

@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <limits>
 
+#include <map>
 #include "stencil.hpp"
 
 namespace fdtdx {
@@ -398,11 +399,12 @@ __global__ void functor_filt_kernel(FunctorGeom g, F f, Args... args)
 
 // The reference's class with its functor-taking methods (template header of stencil.h:357).
 template <typename DataType, size_t ZSize, size_t YSize, size_t XSize, size_t M, bool FDTD = true, typename gpu_size_t = uint32_t,
-          typename gpu_signed_size_t = int32_t>
-class FunctorStencil : public Stencil<DataType, ZSize, YSize, XSize, M, FDTD> {
-    using Base = Stencil<DataType, ZSize, YSize, XSize, M, FDTD>;
+          typename gpu_signed_size_t = int32_t, size_t BLOCK_SIZE = 32, size_t THREADS = 256, size_t PADDINGL = 0, size_t PADDINGR = 0>
+class FunctorStencil : public Stencil<DataType, ZSize, YSize, XSize, M, FDTD, gpu_size_t, gpu_signed_size_t, BLOCK_SIZE, THREADS, PADDINGL, PADDINGR> {
+    using Base = Stencil<DataType, ZSize, YSize, XSize, M, FDTD, gpu_size_t, gpu_signed_size_t, BLOCK_SIZE, THREADS, PADDINGL, PADDINGR>;
 
     hipStream_t stream_ = nullptr;
+    std::map<std::string, std::pair<void *, size_t>> flat_;  // malloc<T>(name, length): flat device buffers (stencil.h:440-447), bytes
 
     FunctorGeom geom(uint64_t z_lo, uint64_t z_hi) const
     {
@@ -446,7 +448,110 @@ public:
     using Base::filt;
     using Base::inject;
     using Base::propagate;
+    using Base::propagateHaloButtomBackup;
+    using Base::propagateHaloTopBackup;
     using Base::propagatePlanes;
+    ~FunctorStencil()
+    {
+        for (auto &kv : flat_) (void)hipFree(kv.second.first);
+    }
+
+    // ---- named flat buffers and address lists (stencil.h:440-551) -------------------------------------------------------
+    // malloc<T>(name, length, is_address): an address list (is_address: indices into the grid, filtered and re-based by
+    // transferToGPU) or a plain device array of `length` T.
+    template <typename T = DataType>
+    T *malloc(const std::string &name, size_t length, bool is_address = false)
+    {
+        if (is_address) {
+            static_assert(sizeof(T) == sizeof(uint64_t) || !std::is_integral<T>::value, "address lists hold 64-bit indices (size_t in main.cu:96)");
+            this->mallocAddr(name, length);
+            return reinterpret_cast<T *>(this->getAddr(name));
+        }
+        if (flat_.count(name)) {
+            std::fprintf(stderr, "ERROR: buffer '%s' exists\n", name.c_str());  // stencil.h:443
+            std::abort();
+        }
+        void *p = nullptr;
+        FDTDX_HIP_ASSERT(hipMalloc(&p, sizeof(T) * std::max<size_t>(length, 1)));
+        flat_[name] = {p, sizeof(T) * length};
+        return static_cast<T *>(p);
+    }
+    template <typename T = DataType>
+    T *get(const std::string &name)
+    {
+        auto it = flat_.find(name);
+        if (it != flat_.end()) return static_cast<T *>(it->second.first);
+        if (sizeof(T) == sizeof(uint64_t) && std::is_integral<T>::value) return reinterpret_cast<T *>(this->getAddr(name));
+        return reinterpret_cast<T *>(this->getCube(name));  // stencil.h:479-484: cubes live in the same pool
+    }
+    // side-buffer twins of an address list (stencil.h:486-498): there are none here
+    template <typename T = DataType>
+    T *getHaloTop(const std::string &)
+    {
+        return nullptr;
+    }
+    template <typename T = DataType>
+    T *getHaloButtom(const std::string &)
+    {
+        return nullptr;
+    }
+    template <typename T>
+    void transferToGPU(const std::string &name, T *cpu, size_t length)
+    {
+        auto it = flat_.find(name);
+        if (it != flat_.end()) {
+            if (sizeof(T) * length > it->second.second) {
+                std::fprintf(stderr, "ERROR: transferToGPU('%s'): %zu bytes into a buffer of %zu\n", name.c_str(), sizeof(T) * length, it->second.second);
+                std::abort();
+            }
+            FDTDX_HIP_ASSERT(hipMemcpy(it->second.first, cpu, sizeof(T) * length, hipMemcpyHostToDevice));
+            return;
+        }
+        // an address list: global unpadded linear indices, kept where this rank owns the plane and re-based (stencil.h:526-543)
+        static_assert(sizeof(T) == sizeof(uint64_t) || !std::is_integral<T>::value, "address lists hold 64-bit indices");
+        this->transferAddrToGPU(name, reinterpret_cast<const uint64_t *>(cpu), length);
+    }
+    template <typename T>
+    void transferToCPU(T *cpu, const std::string &name, size_t length)
+    {
+        auto it = flat_.find(name);
+        const void *src = it != flat_.end() ? it->second.first : static_cast<const void *>(this->getAddr(name));
+        FDTDX_HIP_ASSERT(hipMemcpy(cpu, src, sizeof(T) * length, hipMemcpyDeviceToHost));
+    }
+    void free(const std::string &name)
+    {
+        auto it = flat_.find(name);
+        if (it == flat_.end()) return Base::free(name);
+        FDTDX_HIP_ASSERT(hipFree(it->second.first));
+        flat_.erase(it);
+    }
+
+    // ---- the side-buffer replay of the reference's multi-rank loop, functor forms (stencil.h:770-808, 825-841) -----------
+    // The reference computes the planes a neighbour needs TWICE per step: first in copies of the slab's first/last 3M
+    // planes (propagateHalo*Backup, then inject and filt replayed on those copies, main.cu:153-158), which it sends while
+    // the main pass runs, then again in the main pass (main.cu:160-163).  The copies exist because the passes are arbitrary
+    // functors that may read what they overwrite (main.cu:118 subtracts the old output), so the early result cannot be
+    // written into the cube itself.  Here the cube has no copies: the functor forms of the replay are accepted and do
+    // nothing (their address lists are empty, getAddrHalo*Size), the main pass computes every owned plane once, and
+    // commCubeHaloBackup sends its boundary planes, stream-ordered behind it, straight into the neighbour's ghost planes.
+    // Same fields as the reference's loop; the exchange follows the main pass instead of running beside it.  (Closed
+    // programs keep the overlap: the fdtdx_program forms of these methods sweep the boundary planes first.)
+    template <typename Function, typename... Arguments, typename = if_functor<Function>>
+    void propagateHaloTopBackup(const std::string &, const std::string &, bool, Function, Arguments...)
+    {
+    }
+    template <typename Function, typename... Arguments, typename = if_functor<Function>>
+    void propagateHaloButtomBackup(const std::string &, const std::string &, bool, Function, Arguments...)
+    {
+    }
+    template <typename Function, typename... Arguments, typename = if_functor<Function>>
+    void filtHaloTopBackup(Function, Arguments...)
+    {
+    }
+    template <typename Function, typename... Arguments, typename = if_functor<Function>>
+    void filtHaloButtomBackup(Function, Arguments...)
+    {
+    }
 
     // The stream the functor launches go to (the reference's templates take no stream: their launches go to the
     // null stream, which is the default here too).  The closed-program methods of the base class take theirs per call.

@@ -159,3 +159,60 @@ def test_rccl_send_recv_on_the_exchange_stream():
         assert torch.equal(cube[:M], before[M:2 * M])              # low ghosts <- first M owned planes
         assert torch.equal(cube[L - M:], before[L - 2 * M:L - M])  # high ghosts <- last M owned planes
         assert torch.equal(cube[M:L - M], before[M:L - M])         # owned planes untouched
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_gather_cube_over_local_slabs(n):
+    """transferCubeToCPU's gather (stencil.h:610-637) inside the library: one call on any slab of the process leaves the
+    whole grid on the host."""
+    Z, Y, X, M = 50, 21, 70, 2
+    rng = np.random.default_rng(11)
+    a = rng.random((Z, Y, X), dtype=np.float32)
+    slabs = make_slabs(Z, Y, X, M, n, {"p0": a})
+    Stencil.commInitLocal(slabs)
+    for st in (slabs[0], slabs[-1]):
+        got = np.zeros_like(a)
+        st.gatherCube(got, "p0")
+        assert np.array_equal(got, a)
+    for s in slabs:
+        s.close()
+
+
+def test_gather_cube_over_rccl_communicator_of_one():
+    """The RCCL form of the gather on a communicator of one rank: the slab's planes go through ncclBroadcast into the
+    staging buffer and are unpadded from there (with more ranks every slab takes that route in turn)."""
+    Z, Y, X, M = 40, 19, 130, 1
+    rng = np.random.default_rng(12)
+    a = rng.random((Z, Y, X), dtype=np.float32)
+    with Stencil(Z, Y, X, M) as st:
+        st.mallocCube("p0")
+        st.transferCubeToGPU("p0", a)
+        st.commInit(Stencil.commUniqueId())
+        got = np.zeros_like(a)
+        st.gatherCube(got, "p0")
+    assert np.array_equal(got, a)
+
+
+@pytest.mark.parametrize("n,steps,own_streams", [(2, 10, False), (3, 9, True), (2, 7, False), (3, 4, False)])
+def test_radius2_fuses_on_slabs_through_a_work_cube(oracle_cpu, n, steps, own_streams):
+    """fdtdx_run_work: the radius-2 star (fdtd2.cu) on slabs with ghost depth 4 runs two steps per launch, hopping p1 -> work ->
+    p1 with one exchange of four planes per hop, and ends bit-equal to the oracle's step-by-step loop (every residue of the step
+    count: the loop closes with one to four single steps, the first of them out of the work cube where the hops end there)."""
+    ghost = 4
+    Z, Y, X = 24 * n + 2 * ghost, 41, 200
+    a, b = oracle_cpu.init_mt(Z, Y, X)
+    prog = make_program("star", radius=2)
+    slabs = make_slabs(Z, Y, X, ghost, n, {"p0": a, "p1": b, "work": np.zeros_like(a)})
+    Stencil.commInitLocal(slabs)
+    streams = [torch.cuda.Stream() for _ in slabs] if own_streams else None
+    Stencil.run(slabs, "p0", "p1", prog, steps, [s.cuda_stream for s in streams] if streams else None, work="work")
+    torch.cuda.synchronize()
+    info = slabs[0].lastLaunchInfo()
+    got0 = np.concatenate([s.downloadOwned("p0") for s in slabs], axis=0)
+    got1 = np.concatenate([s.downloadOwned("p1") for s in slabs], axis=0)
+    for s in slabs:
+        s.close()
+    oracle_cpu.run("star", a, b, steps, M=2, order=oracle_cpu.ORDER_CHAIN)
+    assert ("fused2" in info) == (steps >= 4 and ((steps // 2 - 1) if steps % 2 == 0 else ((steps - 1) // 2) & ~1) > 0), info
+    assert np.array_equal(got0.view(np.uint32), a.view(np.uint32)), info
+    assert np.array_equal(got1.view(np.uint32), b.view(np.uint32)), info

@@ -10,7 +10,7 @@ from fdtd_amd import Stencil, make_program, ORDER_CHAIN, ORDER_GOLDEN
 pytestmark = pytest.mark.gpu
 
 
-def run(cpu, kind, shape, steps, tb_variant=-1, tb_zchunks=0, temporal=1, M=1, golden=False):
+def run(cpu, kind, shape, steps, tb_variant=-1, tb_zchunks=0, temporal=1, M=1, golden=False, fuse_wide=0):
     Z, Y, X = shape
     if kind == "jacobi7":
         a = cpu.init_jacobi(Z, Y, X)
@@ -27,6 +27,7 @@ def run(cpu, kind, shape, steps, tb_variant=-1, tb_zchunks=0, temporal=1, M=1, g
         st.setOption("temporal", temporal)
         st.setOption("tb_variant", tb_variant)
         st.setOption("tb_zchunks", tb_zchunks)
+        st.setOption("fuse_wide", fuse_wide)
         st.sweep("p0", "p1", make_program(kind, radius=M, order=ORDER_GOLDEN if golden else ORDER_CHAIN), steps)
         st.sync()
         ga, gb = np.empty_like(a), np.empty_like(b)
@@ -97,6 +98,25 @@ def test_fused_radius2_step_counts(oracle_cpu, steps):
                                    (9, 30, 1531)])
 def test_fused_radius2_small_ragged_wide(oracle_cpu, shape):
     run(oracle_cpu, "star", shape, 7, M=2)
+
+
+@pytest.mark.parametrize("steps", [4, 5, 6, 7, 8, 9, 11])
+@pytest.mark.parametrize("M", [3, 4])
+def test_fused_radius3_and_4_step_counts(oracle_cpu, M, steps):
+    """The two-step kernels of radius 3 and 4 (tbm_kernel.h with three rows per wave; behind the "fuse_wide" option because they
+    run slower than single steps): bit-equal to the step-by-step loop at every residue of the step count, several y tiles and
+    z chunks, ragged x; without the option the same loop runs single steps."""
+    info = run(oracle_cpu, "star", (8 * M + 5, 61, 253), steps, tb_zchunks=2, M=M, fuse_wide=1)
+    assert "fused2" in info and f"r={M}" in info.split("|")[-1]
+    assert "fused" not in run(oracle_cpu, "star", (8 * M + 5, 61, 253), steps, M=M)
+
+
+@pytest.mark.parametrize("M", [3, 4])
+@pytest.mark.parametrize("shape", [(9, 9, 9), (11, 13, 17), (13, 20, 21), (40, 19, 300), (13, 130, 64), (31, 11, 40), (11, 30, 513), (11, 30, 1024),
+                                   (11, 30, 1531), (21, 40, 512)])
+def test_fused_radius3_and_4_small_ragged_wide(oracle_cpu, M, shape):
+    """...on small and ragged grids and on rows cut into x tiles, which overlap by two quads on each side at these radii."""
+    run(oracle_cpu, "star", shape, 7, M=M, fuse_wide=1)
 
 
 @pytest.mark.parametrize("golden", [False, True], ids=["device-order", "golden-order"])
