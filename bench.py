@@ -187,9 +187,11 @@ def main():
     ap.add_argument("--no-standing-start", dest="standing_start", action="store_false",
                     help="skip the extra 1000-step run from a standing start (one rank, sweep variants)")
     ap.add_argument("--all-variants", action="store_true", help="also time every other variant (N=1 only)")
-    ap.add_argument("--exchange", default="native", choices=["native", "torch"],
+    ap.add_argument("--exchange", default="native", choices=["native", "ipc", "torch"],
                     help="N > 1: who moves the ghost planes -- native: the library's own RCCL send/recv on its exchange stream "
-                         "(fdtdx_run); torch: torch.distributed P2P ops issued from Python (fdtd_amd.slab.SlabRunner)")
+                         "(fdtdx_run); ipc: the library's copy transport (neighbours' cubes mapped between the processes, planes pushed by "
+                         "device copies, no exchange kernel on any CU; falls back to native); torch: torch.distributed P2P ops issued "
+                         "from Python (fdtd_amd.slab.SlabRunner)")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="run the N>1 loop with every rank on cuda:0 and host-staged gloo exchange (1-GPU box rehearsal; "
                          "the line is marked rehearsal and is not a measurement)")
@@ -406,7 +408,8 @@ def main():
         n = a.n
         # ghost depth: the program radius, or, on several slabs, what the fused kernels need to run with one
         # exchange per launch: 3 for radius-1 programs (three steps), 4 for radius 2 (two steps)
-        native = world > 1 and a.exchange == "native" and not a.rehearse_shared_gpu
+        use_ipc = world > 1 and a.exchange == "ipc"  # works between processes that share a GPU too
+        native = world > 1 and a.exchange in ("native", "ipc") and not a.rehearse_shared_gpu
         ghost = radius
         if world > 1 and a.temporal != 0:
             if kind in ("star", "jacobi7") and radius == 1:
@@ -439,11 +442,40 @@ def main():
             be.st.setOption("fuse_wide", 1)
             be.alloc("work")
             work = "work"
-        if native and a.temporal != 0 and kind == "star" and radius == 2:
+        if (native or use_ipc) and a.temporal != 0 and kind == "star" and radius == 2:
             be.alloc("work")
             work = "work"
         run = SlabRunner(be, ghost, prog, rank, world, exchange="host" if a.rehearse_shared_gpu else "device")
         cs = torch.cuda.current_stream().cuda_stream
+        flag_dev = "cpu" if a.rehearse_shared_gpu else "cuda"  # where the ranks' agreement flags live (gloo / nccl process group)
+        if use_ipc:
+            # the copy transport: every rank exports the cubes it exchanges, torch.distributed carries the descriptors around,
+            # every rank maps its neighbours' cubes; all ranks take this path or none does
+            ok = torch.ones(1, device=flag_dev)
+            desc = None
+            try:
+                desc = be.st.commIpcExport(["p0", "p1"] + (["work"] if work else []))
+            except Exception as e:
+                print(f"rank {rank}: IPC export failed ({e})", file=sys.stderr)
+                ok.zero_()
+            descs = [None] * world
+            dist.all_gather_object(descs, desc)
+            if ok.item() != 0 and all(d is not None for d in descs):
+                try:
+                    be.st.commIpcConnect(descs[rank - 1] if rank > 0 else None, descs[rank + 1] if rank < world - 1 else None)
+                except Exception as e:
+                    print(f"rank {rank}: IPC connect failed ({e})", file=sys.stderr)
+                    ok.zero_()
+            else:
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            dist.barrier()
+            if ok.item() == 0:
+                use_ipc = False
+                be.st.commDestroy()
+                a.exchange = "native" if native else "torch"
+            else:
+                native = False
         if native:
             # the library's own communicator: rank 0 makes the id, torch.distributed carries its 128 bytes to the others
             ok = torch.ones(1, device="cuda")
@@ -473,7 +505,7 @@ def main():
                 # one rank: the whole time loop runs inside the library (fdtdx_sweep, the drivers'
                 # loop of fdtd1.cu:68-80), which fuses two steps per launch where it can
                 be.st.sweep("p0", "p1", prog, k, cs, work=work)
-            elif native:
+            elif native or use_ipc:
                 Stencil.run([be.st], "p0", "p1", prog, k, [cs], work=work)
             else:
                 run.run("p0", "p1", k, fuse=a.temporal != 0)
@@ -654,12 +686,14 @@ def main():
             line["cpu_baseline"] = {"value": None, "unit": "Gcell/s", "cores": 0, "kind": "reference",
                                     "sample": f"failed: {e}"}
     if a.rehearse_shared_gpu:
-        line["rehearsal"] = "ranks share one GPU, host-staged gloo exchange: NOT a measurement"
+        line["rehearsal"] = ("ranks share one GPU" + (", planes copied between the processes' mapped cubes (IPC)" if a.exchange == "ipc" else ", host-staged gloo exchange")
+                             + ": NOT a measurement")
     if world > 1:
         who = [None] * world
         dist.all_gather_object(who, {"rank": rank, "device": local_rank, "name": torch.cuda.get_device_name(local_rank)})
         line["ranks"] = who
-        line["config"]["exchange"] = ("host-staged gloo (rehearsal)" if a.rehearse_shared_gpu else
+        line["config"]["exchange"] = ("host-staged gloo (rehearsal)" if (a.rehearse_shared_gpu and a.exchange != "ipc") else
+                                      "device copies into the neighbours' mapped cubes (IPC), issued by the library on its exchange stream, hosts pacing" if a.exchange == "ipc" else
                                       "RCCL send/recv issued by the library on its exchange stream" if (a.exchange == "native" and r.get("exchange", "native") == "native")
                                       else "torch.distributed batch_isend_irecv on the nccl (= RCCL) backend")
         line["config"]["world_size"] = dist.get_world_size()

@@ -19,14 +19,30 @@
 //     librccl is opened at run time, so the rest of the library works where it is absent.
 //   * local (all slabs in one process): hipMemcpyPeerAsync / device-to-device copies on the exchange stream.  The
 //     host issues the slabs one after the other, so a step has two phases: begin on every slab, then end on every slab.
+//   * IPC (one process per GPU, no kernel of the exchange on any CU): every rank maps its neighbours' cubes
+//     (hipIpcGetMemHandle / hipIpcOpenMemHandle) and PUSHES its boundary planes into their ghost planes with copies on
+//     the exchange stream, beside its interior sweep.  The hosts pace the exchange, as the reference's do with their
+//     blocking MPI calls while the kernels run (fdtd1.cu:74-76): a rank's host waits for its own copies to land, says so in
+//     a word of shared memory, and waits for its neighbours' word before it queues the next step.  The interior sweep
+//     outlasts the copies, so the next step is queued while it still runs and the device does not idle.  The sweeps fill
+//     every CU with one workgroup, which is what starves RCCL's send/recv kernels beside them; copies need none.
 #include "fdtdx_ctx.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <rccl/rccl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
 
 namespace {
 
@@ -84,7 +100,13 @@ int rccl(RcclApi **out)
 
 }  // namespace
 
-enum { COMM_LOCAL = 0, COMM_RCCL = 1 };
+enum { COMM_LOCAL = 0, COMM_RCCL = 1, COMM_IPC = 2 };
+
+// what a rank in IPC mode shares with its neighbours through POSIX shared memory
+struct IpcShared {
+    std::atomic<uint64_t> landed[2];  // exchanges whose copies towards the neighbour below / above have completed
+    std::atomic<uint64_t> arrived;    // barriers this rank has entered
+};
 
 struct fdtdx_comm {
     int mode = COMM_LOCAL;
@@ -106,6 +128,13 @@ struct fdtdx_comm {
     int comm_rank = -1, comm_size = 0;
     // local
     fdtdx_ctx *nb[2] = {nullptr, nullptr};
+    // IPC
+    char shm_name[64] = "";
+    IpcShared *self_sh = nullptr, *peer_sh[2] = {nullptr, nullptr};
+    std::map<std::string, float *> peer_cube[2];  // the neighbours' cubes as mapped into this process
+    std::vector<void *> opened;                    // what hipIpcOpenMemHandle returned (closed on release)
+    fdtdx_geometry peer_g[2];
+    uint64_t barriers = 0;
 };
 
 // Streams share a few hardware queues, and a wait blocks everything queued behind it in its hardware queue.  The runtime
@@ -159,6 +188,13 @@ void fdtdx_comm_release(fdtdx_ctx *ctx)
     if (c->bs) (void)hipStreamDestroy(c->bs);
     if (c->xs) (void)hipStreamDestroy(c->xs);
     if (c->token) (void)hipFree(c->token);
+    for (void *p : c->opened) (void)hipIpcCloseMemHandle(p);
+    for (int s = 0; s < 2; s++)
+        if (c->peer_sh[s]) munmap(c->peer_sh[s], sizeof(IpcShared));
+    if (c->self_sh) {
+        munmap(c->self_sh, sizeof(IpcShared));
+        shm_unlink(c->shm_name);
+    }
     // a neighbour in this process must not keep pointing here
     for (int s = 0; s < 2; s++)
         if (c->nb[s] && c->nb[s]->comm && c->nb[s]->comm->nb[1 - s] == ctx) c->nb[s]->comm->nb[1 - s] = nullptr;
@@ -292,6 +328,129 @@ extern "C" int fdtdx_comm_init_local(fdtdx_ctx *const *ctxs, int n)
     return FDTDX_OK;
 }
 
+// ---- IPC transport: set-up ---------------------------------------------------------------------------------------
+static_assert(sizeof(hipIpcMemHandle_t) <= sizeof(((fdtdx_ipc_desc *)nullptr)->cube[0].handle), "fdtdx_ipc_desc carries a hipIpcMemHandle_t per cube");
+static_assert(sizeof(fdtdx_ipc_desc) == 976, "launchers pass descriptors around as 976 plain bytes");
+
+extern "C" int fdtdx_comm_ipc_export(fdtdx_ctx *ctx, const char *const *names, int n, fdtdx_ipc_desc *out)
+{
+    if (!ctx || !names || !out || n < 1) return fail(FDTDX_ERR_INVALID, "null argument");
+    if (n > FDTDX_IPC_MAX_CUBES) return fail(FDTDX_ERR_UNSUPPORTED, "at most %d cubes per descriptor", FDTDX_IPC_MAX_CUBES);
+    if (ctx->comm) return fail(FDTDX_ERR_EXISTS, "the context already has a communicator");
+    memset(out, 0, sizeof(*out));
+    fdtdx_comm *c = new (std::nothrow) fdtdx_comm;
+    if (!c) return fail(FDTDX_ERR_NOMEM, "out of host memory");
+    c->mode = COMM_IPC;
+    ctx->comm = c;
+    int rc = comm_streams(ctx, c);
+    if (rc) {
+        fdtdx_comm_release(ctx);
+        return rc;
+    }
+    static std::atomic<unsigned> serial{0};
+    snprintf(c->shm_name, sizeof(c->shm_name), "/fdtdx_%d_%u_%u", (int)getpid(), ctx->cfg.rank, serial++);
+    const int fd = shm_open(c->shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, sizeof(IpcShared)) != 0) {
+        if (fd >= 0) close(fd), shm_unlink(c->shm_name);
+        c->shm_name[0] = 0;
+        fdtdx_comm_release(ctx);
+        return fail(FDTDX_ERR_HIP, "shared memory segment for the exchange could not be created");
+    }
+    void *m = mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) {
+        shm_unlink(c->shm_name);
+        fdtdx_comm_release(ctx);
+        return fail(FDTDX_ERR_HIP, "mmap of the exchange's shared memory failed");
+    }
+    c->self_sh = new (m) IpcShared;
+    c->self_sh->landed[0] = 0, c->self_sh->landed[1] = 0, c->self_sh->arrived = 0;
+    out->rank = ctx->cfg.rank, out->ncubes = (uint32_t)n, out->pid = (int32_t)getpid();
+    memcpy(out->shm_name, c->shm_name, sizeof(out->shm_name));
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+        fdtdx_comm_release(ctx);
+        return fail(FDTDX_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    }
+    for (int i = 0; i < n; i++) {
+        float *p;
+        if ((rc = fdtdx_find_cube(ctx, names[i], &p))) {
+            fdtdx_comm_release(ctx);
+            return rc;
+        }
+        if (strlen(names[i]) >= sizeof(out->cube[i].name)) {
+            fdtdx_comm_release(ctx);
+            return fail(FDTDX_ERR_UNSUPPORTED, "cube name '%s' too long for a descriptor", names[i]);
+        }
+        // the handle names the whole allocation the cube lies in (a cube attached from a caching allocator is a piece of one)
+        hipDeviceptr_t base = nullptr;
+        size_t span = 0;
+        hipIpcMemHandle_t h;
+        hipError_t e = hipMemGetAddressRange(&base, &span, (hipDeviceptr_t)p);
+        if (e == hipSuccess) e = hipIpcGetMemHandle(&h, (void *)base);
+        if (e != hipSuccess) {
+            fdtdx_comm_release(ctx);
+            return fail(FDTDX_ERR_HIP, "no inter-process handle for cube '%s': %s", names[i], hipGetErrorString(e));
+        }
+        strcpy(out->cube[i].name, names[i]);
+        memcpy(out->cube[i].handle, &h, sizeof(h));
+        out->cube[i].offset = (uint64_t)((char *)p - (char *)base);
+        out->cube[i].bytes = ctx->g.cube_elems * sizeof(float);
+    }
+    return FDTDX_OK;
+}
+
+extern "C" int fdtdx_comm_ipc_connect(fdtdx_ctx *ctx, const fdtdx_ipc_desc *lo, const fdtdx_ipc_desc *hi)
+{
+    if (!ctx || !ctx->comm || ctx->comm->mode != COMM_IPC) return fail(FDTDX_ERR_INVALID, "call fdtdx_comm_ipc_export on this context first");
+    fdtdx_comm *c = ctx->comm;
+    const fdtdx_ipc_desc *d[2] = {lo, hi};
+    const bool need[2] = {ctx->g.ghost_lo != 0, ctx->g.ghost_hi != 0};
+    USE_DEVICE(ctx);
+    for (int s = 0; s < 2; s++) {
+        if (!need[s]) continue;
+        if (!d[s]) return fail(FDTDX_ERR_INVALID, "no descriptor of the neighbour %s", s ? "above" : "below");
+        const uint32_t want = s ? ctx->cfg.rank + 1 : ctx->cfg.rank - 1;
+        if (d[s]->rank != want || d[s]->ncubes > FDTDX_IPC_MAX_CUBES) return fail(FDTDX_ERR_INVALID, "descriptor of rank %u where rank %u's is needed", d[s]->rank, want);
+        if (c->peer_sh[s]) return fail(FDTDX_ERR_EXISTS, "already connected");
+        fdtdx_config cf = ctx->cfg;
+        cf.rank = want;
+        int rc = fdtdx_decompose(&cf, &c->peer_g[s]);
+        if (rc) return rc;
+        char name[sizeof(d[s]->shm_name) + 1] = "";
+        memcpy(name, d[s]->shm_name, sizeof(d[s]->shm_name));
+        const int fd = shm_open(name, O_RDWR, 0600);
+        if (fd < 0) return fail(FDTDX_ERR_HIP, "cannot open the neighbour's shared memory '%s'", name);
+        void *m = mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) return fail(FDTDX_ERR_HIP, "mmap of the neighbour's shared memory failed");
+        c->peer_sh[s] = (IpcShared *)m;
+        for (uint32_t i = 0; i < d[s]->ncubes; i++) {
+            if (d[s]->cube[i].bytes != c->peer_g[s].cube_elems * sizeof(float)) return fail(FDTDX_ERR_INVALID, "the neighbour's cube '%.31s' has another geometry", d[s]->cube[i].name);
+            hipIpcMemHandle_t h;
+            memcpy(&h, d[s]->cube[i].handle, sizeof(h));
+            void *base = nullptr;
+            const hipError_t e = hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) return fail(FDTDX_ERR_HIP, "hipIpcOpenMemHandle for the neighbour's cube '%.31s': %s", d[s]->cube[i].name, hipGetErrorString(e));
+            c->opened.push_back(base);
+            c->peer_cube[s][std::string(d[s]->cube[i].name, strnlen(d[s]->cube[i].name, sizeof(d[s]->cube[i].name)))] = (float *)((char *)base + d[s]->cube[i].offset);
+        }
+    }
+    return FDTDX_OK;
+}
+
+// host side of an IPC-mode wait: until `word` reaches `want` (the neighbour's host says so); false after `limit_s` seconds
+static bool ipc_await(const std::atomic<uint64_t> &word, uint64_t want, double limit_s)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; word.load(std::memory_order_acquire) < want; spins++) {
+        if ((spins & 0x3ff) == 0x3ff) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) return false;
+            std::this_thread::yield();
+        }
+    }
+    return true;
+}
+
 extern "C" int fdtdx_comm_boundary_done(fdtdx_ctx *ctx, void *stream)
 {
     if (!ctx || !ctx->comm) return fail(FDTDX_ERR_INVALID, "the context has no communicator");
@@ -342,6 +501,21 @@ extern "C" int fdtdx_comm_exchange_start(fdtdx_ctx *ctx, const char *name, void 
             c->broken = true;
             return fail(FDTDX_ERR_HIP, "RCCL send/recv group of the ghost-plane exchange: %s", api->GetErrorString(first));
         }
+    } else if (c->mode == COMM_IPC) {
+        // push: this rank's boundary planes into the neighbour's ghost planes on the side that faces this rank.  What the
+        // copy overwrites there the neighbour last read in the boundary sweep of its previous step, and that sweep had
+        // finished before the neighbour pushed the planes this rank's own boundary sweep (queued ahead of this copy) has
+        // just read: nothing more to wait for.
+        for (int s = 0; s < 2; s++) {
+            if (!cnt[s]) continue;
+            auto it = c->peer_cube[s].find(name);
+            if (!c->peer_sh[s] || it == c->peer_cube[s].end()) return fail(FDTDX_ERR_INVALID, "cube '%s' of the neighbour %s is not mapped (fdtdx_comm_ipc_export / _connect)", name, s ? "above" : "below");
+            const fdtdx_geometry &pg = c->peer_g[s];
+            const uint64_t depth = s ? pg.ghost_lo : pg.ghost_hi;  // its ghost planes towards this rank
+            if (depth * pg.plane != cnt[s]) return fail(FDTDX_ERR_INVALID, "the neighbouring slab has another geometry");
+            float *dst = it->second + (s ? 0 : (pg.local_planes - pg.ghost_hi) * pg.plane);
+            HIP_TRY(hipMemcpyAsync(dst, snd[s], cnt[s] * sizeof(float), hipMemcpyDeviceToDevice, c->xs));
+        }
     } else {
         for (int s = 0; s < 2; s++) {
             fdtdx_ctx *o = c->nb[s];
@@ -384,6 +558,22 @@ extern "C" int fdtdx_comm_exchange_wait(fdtdx_ctx *ctx, void *stream)
     if (c->waited == c->epoch) return FDTDX_OK;  // nothing in flight
     USE_DEVICE(ctx);
     hipStream_t st = (hipStream_t)stream;
+    if (c->mode == COMM_IPC) {
+        // the hosts pace the exchange: this rank's copies have landed (it says so), then its neighbours' (they say so);
+        // what the caller queues after this call is queued after both
+        if (c->broken) return fail(FDTDX_ERR_HIP, "an earlier exchange of this communicator failed");
+        HIP_TRY(hipStreamSynchronize(c->xs));
+        for (int s = 0; s < 2; s++)
+            if (c->peer_sh[s]) c->self_sh->landed[s].store(c->epoch, std::memory_order_release);
+        for (int s = 0; s < 2; s++)
+            if (c->peer_sh[s] && !ipc_await(c->peer_sh[s]->landed[1 - s], c->epoch, 60.0)) {
+                c->broken = true;
+                return fail(FDTDX_ERR_HIP, "the neighbour %s has not delivered exchange %llu within 60 s", s ? "above" : "below", (unsigned long long)c->epoch);
+            }
+        c->waited = c->epoch;
+        c->last_stream = st;
+        return FDTDX_OK;
+    }
     HIP_TRY(hipStreamWaitEvent(st, c->done, 0));  // RCCL: sends and receives; local: the copies out of this cube
     if (c->mode == COMM_LOCAL)
         for (int s = 0; s < 2; s++) {  // the copies INTO this cube are the neighbours' work
@@ -425,6 +615,13 @@ extern "C" int fdtdx_comm_barrier(fdtdx_ctx *ctx)
         HIP_TRY(hipSetDevice(ctx->device));
         return FDTDX_OK;
     }
+    if (c->mode == COMM_IPC) {  // this rank and both its neighbours have drained their devices and arrived
+        const uint64_t n = ++c->barriers;
+        c->self_sh->arrived.store(n, std::memory_order_release);
+        for (int s = 0; s < 2; s++)
+            if (c->peer_sh[s] && !ipc_await(c->peer_sh[s]->arrived, n, 120.0)) return fail(FDTDX_ERR_HIP, "the neighbour %s has not reached barrier %llu within 120 s", s ? "above" : "below", (unsigned long long)n);
+        return FDTDX_OK;
+    }
     RcclApi *api;
     int rc = rccl(&api);
     if (rc) return rc;
@@ -463,6 +660,7 @@ extern "C" int fdtdx_gather_cube(fdtdx_ctx *ctx, float *host, const char *name)
         if (hipSetDevice(ctx->device) != hipSuccess) (void)hipGetLastError();
         return rc;
     }
+    if (c->mode == COMM_IPC) return fail(FDTDX_ERR_UNSUPPORTED, "fdtdx_gather_cube: ranks in IPC mode map their neighbours only; gather with the launcher's communicator");
     // RCCL: the communicator must be the one fdtdx_comm_init makes (communicator rank == slab rank)
     const int n = (int)ctx->cfg.nprocs;
     if (c->comm_size != n || c->comm_rank != (int)ctx->cfg.rank)
@@ -621,6 +819,7 @@ extern "C" int fdtdx_yee3d_slab_half_begin(fdtdx_ctx *ctx, const char *const fie
     c->marked = false;
     HIP_TRY(hipStreamWaitEvent(c->xs, c->ready, 0));
     const size_t cnt = (size_t)g.plane;
+    if (c->mode == COMM_IPC) return fail(FDTDX_ERR_UNSUPPORTED, "the E/H half step moves single planes of two fields: RCCL or local transport only");
     if (c->mode == COMM_RCCL) {
         RcclApi *api;
         if ((rc = rccl(&api))) return rc;

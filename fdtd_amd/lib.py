@@ -110,6 +110,8 @@ SYMBOLS = {
     "fdtdx_comm_init_ranks": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "fdtdx_comm_init_local": (ctypes.c_int, [_P(_vp), ctypes.c_int]),
     "fdtdx_comm_destroy": (ctypes.c_int, [_vp]),
+    "fdtdx_comm_ipc_export": (ctypes.c_int, [_vp, _P(_c), ctypes.c_int, _vp]),
+    "fdtdx_comm_ipc_connect": (ctypes.c_int, [_vp, _vp, _vp]),
     "fdtdx_comm_barrier": (ctypes.c_int, [_vp]),
     "fdtdx_comm_state": (ctypes.c_int, [_vp, _c, ctypes.c_size_t]),
     "fdtdx_comm_boundary_done": (ctypes.c_int, [_vp, _vp]),
@@ -128,6 +130,8 @@ SYMBOLS = {
     "fdtdx_set_option": (ctypes.c_int, [_vp, _c, ctypes.c_int64]),
     "fdtdx_last_launch_info": (ctypes.c_int, [_vp, _c, ctypes.c_size_t]),
 }
+
+IPC_DESC_BYTES = 976  # sizeof(fdtdx_ipc_desc)
 
 _lib = None
 

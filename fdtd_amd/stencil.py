@@ -282,6 +282,24 @@ class Stencil:
         arr = (ctypes.c_void_p * len(stencils))(*[s._h for s in stencils])
         _lib.check(_lib.load().fdtdx_comm_init_local(arr, len(stencils)))
 
+    def commIpcExport(self, names):
+        """IPC transport, step 1 (fdtdx_comm_ipc_export): the descriptor of this rank's cubes `names`, as bytes for the launcher
+        to hand to the neighbouring ranks."""
+        arr = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])
+        buf = ctypes.create_string_buffer(_lib.IPC_DESC_BYTES)
+        _lib.check(self._L.fdtdx_comm_ipc_export(self._h, arr, len(names), buf))
+        return buf.raw
+
+    def commIpcConnect(self, lo, hi):
+        """IPC transport, step 2 (fdtdx_comm_ipc_connect): the descriptors (bytes) of the neighbours below / above, None where
+        there is none."""
+        keep = [ctypes.create_string_buffer(bytes(d), _lib.IPC_DESC_BYTES) if d is not None else None for d in (lo, hi)]
+        _lib.check(self._L.fdtdx_comm_ipc_connect(self._h, keep[0], keep[1]))
+
+    def commDestroy(self):
+        """Drop this slab's communicator (fdtdx_comm_destroy); another transport can be set up afterwards."""
+        _lib.check(self._L.fdtdx_comm_destroy(self._h))
+
     def commState(self):
         """Which exchange events have fired / which streams are idle, as text (fdtdx_comm_state; queries only)."""
         buf = ctypes.create_string_buffer(640)

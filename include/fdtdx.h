@@ -232,6 +232,29 @@ int fdtdx_comm_init(fdtdx_ctx *ctx, const fdtdx_comm_id *id);
 int fdtdx_comm_init_ranks(fdtdx_ctx *ctx, const fdtdx_comm_id *id, int comm_rank, int comm_size, int peer_lo, int peer_hi);
 int fdtdx_comm_init_local(fdtdx_ctx *const *ctxs, int n);
 int fdtdx_comm_destroy(fdtdx_ctx *ctx); /* fdtdx_destroy does it too */
+/* A third transport for one process per GPU, with no kernel of the exchange on any CU: every rank maps its neighbours'
+ * cubes into its own address space and pushes its boundary planes into their ghost planes with copies on its exchange
+ * stream, beside its interior sweep; the hosts pace the exchange through a word of shared memory, as the reference's hosts
+ * do with blocking MPI calls while their kernels run (fdtd1.cu:74-76; fdtdx_comm_exchange_wait / fdtdx_step_end block the
+ * calling thread in this mode until this rank's copies and its neighbours' have landed).  Set-up: every rank calls
+ * fdtdx_comm_ipc_export for the cubes it will exchange (all allocated already), the launcher hands each rank the
+ * descriptors of its neighbours (plain bytes: a file, a pipe, torch.distributed), every rank calls
+ * fdtdx_comm_ipc_connect (NULL where there is no neighbour).  Ranks must be processes of one machine.  The exchange relies
+ * on the boundary-first step order of fdtdx_step_begin / fdtdx_hop_begin / fdtdx_run (a neighbour's ghost planes are
+ * overwritten only after the neighbour has read them); fdtdx_gather_cube and the E/H half step are not available. */
+#define FDTDX_IPC_MAX_CUBES 8
+typedef struct fdtdx_ipc_desc {
+    uint32_t rank, ncubes;
+    int32_t pid, reserved;
+    char shm_name[64];
+    struct {
+        char name[32];
+        char handle[64];
+        uint64_t offset, bytes;
+    } cube[FDTDX_IPC_MAX_CUBES];
+} fdtdx_ipc_desc;
+int fdtdx_comm_ipc_export(fdtdx_ctx *ctx, const char *const *names, int n, fdtdx_ipc_desc *out);
+int fdtdx_comm_ipc_connect(fdtdx_ctx *ctx, const fdtdx_ipc_desc *lo, const fdtdx_ipc_desc *hi);
 /* Stencil::barrier (stencil.h:435-438): this slab's queued work has finished and every slab of the chain has arrived. */
 int fdtdx_comm_barrier(fdtdx_ctx *ctx);
 /* Diagnostic: one line of text saying which of this slab's exchange events have fired and which of its streams are idle
