@@ -75,6 +75,13 @@ constexpr int star_nhk(int M, int TQ, int LY, int RY)
 #ifndef FDTDX_RING_MIN_M
 #define FDTDX_RING_MIN_M 3
 #endif
+// Timing experiments only (results are wrong with any bit set): which part of a plane step costs what.
+//   1: no neighbour reads and no arithmetic (the result is the own quad)      2: the halo quads skip the LDS ring (dropped)
+//   4: no halo loads        8: no re-read of the output's shell components    16: no store        32: no LDS publish, no barrier
+//   64: the y neighbours are not read from LDS (the own quad stands in: same arithmetic)   128: nor the x neighbours
+#ifndef FDTDX_ABLATE
+#define FDTDX_ABLATE 0
+#endif
 // quads of a ring of `planes` planes: the halo quads of each plane, and one spare quad for every thread that has no halo
 // quad in its last round (it parks the zeros its masked load returns there, so that the ring traffic needs no branch)
 constexpr int star_ring_quads(int M, int TQ, int LY, int RY, int planes)
@@ -136,9 +143,13 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
 #define QS(k) (((k) + PH) % QT)
 
     // publish the centre plane + halo
+    if constexpr (!(FDTDX_ABLATE & 32)) {
 #pragma unroll
-    for (int j = 0; j < RY; j++) buf[L.lown[j]] = q[j][QS(M)];
-    if constexpr (RP > 0) {
+        for (int j = 0; j < RY; j++) buf[L.lown[j]] = q[j][QS(M)];
+    }
+    if constexpr ((FDTDX_ABLATE & 2) != 0) {
+        // halo quads go nowhere
+    } else if constexpr (RP > 0) {
         // the halo of this plane leaves the ring; its slot takes the halo of plane z+M+PF-1, which the step before fetched
 #pragma unroll
         for (int k = 0; k < NHK; k++) {
@@ -181,13 +192,17 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
             cs.sq[j] = buf_ld4s(rs, L.soff[j]);
         }
     }
+    if constexpr (!(FDTDX_ABLATE & 4)) {
 #pragma unroll
-    for (int k = 0; k < NHK; k++)  // ring: only planes that become a centre plane of this chunk need their halo
-        hv[k] = RP > 0 ? buf_ld4(rn, more_h ? L.hgoff[k] : OOB) : buf_ld4(rc, L.hgoff[k]);
+        for (int k = 0; k < NHK; k++)  // ring: only planes that become a centre plane of this chunk need their halo
+            hv[k] = RP > 0 ? buf_ld4(rn, more_h ? L.hgoff[k] : OOB) : buf_ld4(rc, L.hgoff[k]);
+    }
+    if constexpr (!(FDTDX_ABLATE & 8)) {
 #pragma unroll
-    for (int j = 0; j < RY; j++)  // streamed past the caches where measured faster: full-row tiles (+2-4 % at radius 1 and 3; 3 % slower with x tiles)
-        eo[j] = (is_composite(ORDER) || TQ >= 128) ? buf_ld4s(ron, L.eoff[j]) : buf_ld4(ron, L.eoff[j]);
-    __syncthreads();
+        for (int j = 0; j < RY; j++)  // streamed past the caches where measured faster: full-row tiles (+2-4 % at radius 1 and 3; 3 % slower with x tiles)
+            eo[j] = (is_composite(ORDER) || TQ >= 128) ? buf_ld4s(ron, L.eoff[j]) : buf_ld4(ron, L.eoff[j]);
+    }
+    if constexpr (!(FDTDX_ABLATE & 32)) __syncthreads();
 
     const float c0 = c[0], cxp = c[1], cxm = c[2], cyp = c[3], cym = c[4], czp = c[5], czm = c[6];
 #pragma unroll
@@ -206,7 +221,7 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
                 asm("" : "+v"(w));
                 v = make_float4(w[0], w[1], w[2], w[3]);
             } else {
-                v = (s == 0) ? q[j][QS(M)] : row[s];
+                v = (s == 0 || (FDTDX_ABLATE & 128)) ? q[j][QS(M)] : row[s];
             }
             xs[4 * (s + HQ) + 0] = v.x;
             xs[4 * (s + HQ) + 1] = v.y;
@@ -270,13 +285,15 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
                 }
                 buf_st4(make_rsrc(cs.ps, plane_bytes), L.soff[j], sv[0], sv[1], sv[2], sv[3]);
             }
+        } else if constexpr ((FDTDX_ABLATE & 1) != 0) {
+            acc[0] = xs[XB] + hv[0].x, acc[1] = xs[XB + 1], acc[2] = xs[XB + 2], acc[3] = xs[XB + 3];  // (the halo loads stay alive)
         } else if constexpr (ORDER == ORD_STAR_CHAIN || ORDER == ORD_STAR_GOLDEN) {
             // two cells per instruction (v_pk_mul/add/fma_f32): cells 0,1 and 2,3 of the quad
 #define XP(i) f32x2{xs[(i)], xs[(i) + 1]}
             f32x2 a01 = c0 * XP(XB), a23 = c0 * XP(XB + 2);
 #pragma unroll
             for (int r = 1; r <= M; r++) {
-                const float4 yp = row[r * LPQ], ym = row[-r * LPQ];
+                const float4 yp = (FDTDX_ABLATE & 64) ? q[j][QS(M)] : row[r * LPQ], ym = (FDTDX_ABLATE & 64) ? q[j][QS(M)] : row[-r * LPQ];
                 const float4 zp = q[j][QS(M + r)], zm = q[j][QS(M - r)];
                 a01 = pair_or_chain2<ORDER>(a01, cxp, XP(XB + r), cxm, XP(XB - r));
                 a01 = pair_or_chain2<ORDER>(a01, cyp, f32x2{yp.x, yp.y}, cym, f32x2{ym.x, ym.y});
@@ -310,8 +327,9 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
                 }
             }
         }
-        buf_st4(ro, L.soff[j], L.m0 ? acc[0] : eo_cur[j].x, L.m1 ? acc[1] : eo_cur[j].y, L.m2 ? acc[2] : eo_cur[j].z,
-                L.m3 ? acc[3] : eo_cur[j].w);
+        // (ablated store: the offset is out of range unless a result is a NaN of one particular payload, which keeps the results alive)
+        buf_st4(ro, (FDTDX_ABLATE & 16) ? (__float_as_uint(acc[0] + acc[1] + acc[2] + acc[3]) == 0x7fc12345u ? L.soff[j] : OOB) : L.soff[j],
+                L.m0 ? acc[0] : eo_cur[j].x, L.m1 ? acc[1] : eo_cur[j].y, L.m2 ? acc[2] : eo_cur[j].z, L.m3 ? acc[3] : eo_cur[j].w);
     }
     pn += pf;
     pc += pf;

@@ -63,3 +63,61 @@ def test_static_scratch_rejects_lists_beyond_its_size():
         # the allocating entry point takes the same list
         st.compositeStep("p0", "p1", "vel", "sum", "addr", make_composite(), 1.0, Z // 2, Y // 3, X // 4, 0.9)
         st.sync()
+
+
+def _fields(shape, naddr, seed):
+    Z, Y, X = shape
+    rng = np.random.default_rng(seed)
+    f = {n: rng.random((Z, Y, X), dtype=np.float32) for n in ("p0", "p1", "vel")}
+    f["sum"] = np.zeros((Z, Y, X), np.float32)
+    return f, rng.integers(0, Z * Y * X, naddr).astype(np.uint64)
+
+
+def test_static_step_is_capturable_where_allocation_is_illegal():
+    """The property the entry point exists for: nothing on its path allocates.  Under stream capture (torch.cuda.graph, error
+    mode "global") hipMalloc is illegal and fails; the static step is captured on a context that has never run a step, the
+    graph replays, and the fields equal those of an eager static step -- while the allocating entry point, on a context in
+    the same state, is refused inside a capture (its first call has to allocate its per-address buffer)."""
+    import torch
+    shape, naddr = (24, 33, 70), 900
+    Z, Y, X = shape
+    fields, addr = _fields(shape, naddr, 5)
+    comp = make_composite()
+    args = ("p0", "p1", "vel", "sum", "addr", comp, 1.0, Z // 2, Y // 3, X // 4, 0.9)
+
+    def context():
+        st = Stencil(Z, Y, X, 4)
+        for n, f in fields.items():
+            st.mallocCube(n)
+            st.transferCubeToGPU(n, f)
+        st.mallocAddr("addr", naddr)
+        st.transferAddrToGPU("addr", addr)
+        return st
+
+    def fetch(st):
+        out = {}
+        for n in ("p0", "sum"):
+            out[n] = np.empty(shape, np.float32)
+            st.transferCubeToCPU(out[n], n)
+        return out
+
+    with context() as ref:  # eager; also loads every kernel of the step before anything is captured
+        ref.compositeStepStatic(*args)
+        ref.sync()
+        want = fetch(ref)
+    with context() as st:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="global"):
+            st.compositeStepStatic(*args, stream=torch.cuda.current_stream().cuda_stream)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = fetch(st)
+        del graph
+    for n in want:
+        assert np.array_equal(got[n].view(np.uint32), want[n].view(np.uint32)), n
+    with context() as st:
+        graph = torch.cuda.CUDAGraph()
+        with pytest.raises((FdtdxError, RuntimeError)):
+            with torch.cuda.graph(graph, capture_error_mode="global"):
+                st.compositeStep(*args, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
