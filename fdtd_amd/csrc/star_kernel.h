@@ -82,6 +82,17 @@ constexpr int star_nhk(int M, int TQ, int LY, int RY)
 #ifndef FDTDX_ABLATE
 #define FDTDX_ABLATE 0
 #endif
+// 1: a step publishes the NEXT centre plane to LDS after its own arithmetic, behind one barrier at the top of the step; 0: it
+// publishes its own centre plane first and meets the barrier before the arithmetic.  The LDS stores of a publish are slow
+// (a 16-byte store takes about 13 cycles to move from the registers, three times a 16-byte read) and nothing of the same wave
+// overlaps them when the barrier follows at once; behind the arithmetic they overlap other waves' reads and multiplies.
+// Measured at 512^3 on fields that stay finite: radius 7 gains 5 % (226 -> 215 us per sweep), radius 6 is level, radius 3-5
+// lose 2-6 % (their halo loads move behind the arithmetic with the publish) and radius 8 does not fit its 128 registers in
+// this order (101 spilled; 268 us with the default scheduler against 249).  So it is a per-radius choice: a translation
+// unit that wants it defines FDTDX_LATE_PUBLISH 1 before it includes this header (star_m7.hip).
+#ifndef FDTDX_LATE_PUBLISH
+#define FDTDX_LATE_PUBLISH 0
+#endif
 // quads of a ring of `planes` planes: the halo quads of each plane, and one spare quad for every thread that has no halo
 // quad in its last round (it parks the zeros its masked load returns there, so that the ring traffic needs no branch)
 constexpr int star_ring_quads(int M, int TQ, int LY, int RY, int planes)
@@ -91,11 +102,11 @@ constexpr int star_ring_quads(int M, int TQ, int LY, int RY, int planes)
 constexpr int star_ring_planes(int M, int TQ, int LY, int RY, int ORDER, int PF)
 {
     const int images = 2 * (LY * RY + 2 * M) * (TQ + 2 * ((M + 3) / 4)) * 16;
-    const int ring = star_ring_quads(M, TQ, LY, RY, M + PF - 1) * 16;
+    const int ring = star_ring_quads(M, TQ, LY, RY, M + PF - 1 - FDTDX_LATE_PUBLISH) * 16;
     // not in the separate-multiply-add order from radius 5 up: those kernels are bound by their arithmetic and registers, and
     // measured 1-10 % slower with the ring's extra LDS traffic (radius 3: 7 % faster, radius 4: level)
     if (ORDER == ORD_STAR_GOLDEN && M >= 5) return 0;
-    return (M >= FDTDX_RING_MIN_M && !is_composite(ORDER) && images + ring <= 160 * 1024) ? M + PF - 1 : 0;
+    return (M >= FDTDX_RING_MIN_M && !is_composite(ORDER) && images + ring <= 160 * 1024) ? M + PF - 1 - FDTDX_LATE_PUBLISH : 0;
 }
 
 // Per-thread constants of the march.
@@ -129,8 +140,8 @@ struct Comp {
 template <int M, int TQ, int LY, int RY, int ORDER, int PF, int PH>
 __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], float4 (&eo)[RY],
                                            float4 (&hv)[star_nhk(M, TQ, LY, RY)], const Lane<RY, star_nhk(M, TQ, LY, RY)> &L,
-                                           float4 *buf, float4 *ring, int &rslot, const float *&pn, const float *&pc, float *&po, const float *&pe,
-                                           long long ep, bool more_n, bool more_c, bool more_h,
+                                           float4 *buf, float4 *bufn, float4 *ring, int &rslot, const float *&pn, const float *&pc, float *&po, const float *&pe,
+                                           long long ep, bool more_n, bool more_c, bool more_c2, bool more_h,
                                            unsigned plane_bytes, const float (&c)[7], Comp<RY> &cs, int gz)
 {
     constexpr int HQ = (M + 3) / 4;
@@ -142,35 +153,45 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
     constexpr int NHQ = star_nhq(M, TQ, LY, RY);
 #define QS(k) (((k) + PH) % QT)
 
-    // publish the centre plane + halo
-    if constexpr (!(FDTDX_ABLATE & 32)) {
+    // publish a centre plane + its halo: this step's own plane into `buf` ahead of the barrier, or (late publish) the next
+    // step's plane into `bufn` behind this step's arithmetic
+    auto publish = [&](float4 *dst, int slot) {
+        if constexpr (!(FDTDX_ABLATE & 32)) {
 #pragma unroll
-        for (int j = 0; j < RY; j++) buf[L.lown[j]] = q[j][QS(M)];
-    }
-    if constexpr ((FDTDX_ABLATE & 2) != 0) {
-        // halo quads go nowhere
-    } else if constexpr (RP > 0) {
-        // the halo of this plane leaves the ring; its slot takes the halo of plane z+M+PF-1, which the step before fetched
-#pragma unroll
-        for (int k = 0; k < NHK; k++) {
-            const int hidx = (int)threadIdx.x + k * NT;
-            float4 *rs = ring + ((k < NHK - 1 || hidx < NHQ) ? rslot * NHQ + hidx : RP * NHQ + hidx - NHQ);
-            const float4 h = *rs;
-            *rs = hv[k];
-            if (L.hloff[k] >= 0) buf[L.hloff[k]] = h;
+            for (int j = 0; j < RY; j++) dst[L.lown[j]] = q[j][slot];
         }
-        rslot = (rslot + 1 == RP) ? 0 : rslot + 1;
-    } else {
+        if constexpr ((FDTDX_ABLATE & 2) != 0) {
+            // halo quads go nowhere
+        } else if constexpr (RP > 0) {
+            // the halo of the published plane leaves the ring; its slot takes the halo the step before fetched
 #pragma unroll
-        for (int k = 0; k < NHK; k++)
-            if (L.hloff[k] >= 0) buf[L.hloff[k]] = hv[k];
+            for (int k = 0; k < NHK; k++) {
+                const int hidx = (int)threadIdx.x + k * NT;
+                float4 *rs = ring + ((k < NHK - 1 || hidx < NHQ) ? rslot * NHQ + hidx : RP * NHQ + hidx - NHQ);
+                const float4 h = *rs;
+                *rs = hv[k];
+                if (L.hloff[k] >= 0) dst[L.hloff[k]] = h;
+            }
+            rslot = (rslot + 1 == RP) ? 0 : rslot + 1;
+        } else {
+#pragma unroll
+            for (int k = 0; k < NHK; k++)
+                if (L.hloff[k] >= 0) dst[L.hloff[k]] = hv[k];
+        }
+    };
+    if constexpr (FDTDX_LATE_PUBLISH) {
+        // plane z is complete in `buf` (the step before, or the prologue, published it) and nobody reads `bufn` any more
+        if constexpr (!(FDTDX_ABLATE & 32)) __syncthreads();
+    } else {
+        publish(buf, QS(M));
     }
 
     // prefetches; where there is no such plane the descriptor is empty and the loads return 0
     const unsigned nbn = more_n ? plane_bytes : 0u, nbc = more_c ? plane_bytes : 0u;
     const long long pf = plane_bytes >> 2;
     const __amdgpu_buffer_rsrc_t rn = make_rsrc(pn, nbn);        // plane z+M+PF
-    const __amdgpu_buffer_rsrc_t rc = make_rsrc(pc + pf, nbc);   // halo of plane z+1
+    // no ring: the halo of the plane the next publish needs -- plane z+1, or (late publish, which works a step ahead) z+2
+    const __amdgpu_buffer_rsrc_t rc = FDTDX_LATE_PUBLISH ? make_rsrc(pc + 2 * pf, more_c2 ? plane_bytes : 0u) : make_rsrc(pc + pf, nbc);
     // shell components of output plane z+1: from the output cube, or from the strip kept beside it
     const __amdgpu_buffer_rsrc_t ron = pe ? make_rsrc(pe + ep, more_c ? (unsigned)(ep * 4) : 0u) : make_rsrc(po + pf, nbc);
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(po, plane_bytes);
@@ -192,17 +213,21 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
             cs.sq[j] = buf_ld4s(rs, L.soff[j]);
         }
     }
-    if constexpr (!(FDTDX_ABLATE & 4)) {
+    auto load_halo = [&]() {
+        if constexpr (!(FDTDX_ABLATE & 4)) {
+            // ring: the halo of the plane the own quads are fetched of (only planes that become a centre plane of this chunk need
+            // one); no ring: the halo of the next plane to be published
 #pragma unroll
-        for (int k = 0; k < NHK; k++)  // ring: only planes that become a centre plane of this chunk need their halo
-            hv[k] = RP > 0 ? buf_ld4(rn, more_h ? L.hgoff[k] : OOB) : buf_ld4(rc, L.hgoff[k]);
-    }
+            for (int k = 0; k < NHK; k++) hv[k] = RP > 0 ? buf_ld4(rn, more_h ? L.hgoff[k] : OOB) : buf_ld4(rc, L.hgoff[k]);
+        }
+    };
+    if constexpr (!FDTDX_LATE_PUBLISH) load_halo();
     if constexpr (!(FDTDX_ABLATE & 8)) {
 #pragma unroll
         for (int j = 0; j < RY; j++)  // streamed past the caches where measured faster: full-row tiles (+2-4 % at radius 1 and 3; 3 % slower with x tiles)
             eo[j] = (is_composite(ORDER) || TQ >= 128) ? buf_ld4s(ron, L.eoff[j]) : buf_ld4(ron, L.eoff[j]);
     }
-    if constexpr (!(FDTDX_ABLATE & 32)) __syncthreads();
+    if constexpr (!FDTDX_LATE_PUBLISH && !(FDTDX_ABLATE & 32)) __syncthreads();
 
     const float c0 = c[0], cxp = c[1], cxm = c[2], cyp = c[3], cym = c[4], czp = c[5], czm = c[6];
 #pragma unroll
@@ -331,6 +356,10 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
         buf_st4(ro, (FDTDX_ABLATE & 16) ? (__float_as_uint(acc[0] + acc[1] + acc[2] + acc[3]) == 0x7fc12345u ? L.soff[j] : OOB) : L.soff[j],
                 L.m0 ? acc[0] : eo_cur[j].x, L.m1 ? acc[1] : eo_cur[j].y, L.m2 ? acc[2] : eo_cur[j].z, L.m3 ? acc[3] : eo_cur[j].w);
     }
+    if constexpr (FDTDX_LATE_PUBLISH) {
+        publish(bufn, QS(M + 1));  // plane z+1: the next step's centre plane (its halo: from the ring, or fetched by the step before)
+        load_halo();
+    }
     pn += pf;
     pc += pf;
     po += pf;
@@ -439,22 +468,33 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
     }
     const float *pc = p.in + (long long)zs * p.plane;  // centre plane
     float *po = p.out + (long long)zs * p.plane;
+    // late publish: the first centre plane and its halo go to LDS here; everything after it is one plane further on
+    constexpr int H0 = FDTDX_LATE_PUBLISH;  // first plane (counted from zs) whose halo a step of the loop publishes
+    if constexpr (FDTDX_LATE_PUBLISH) {
+#pragma unroll
+        for (int j = 0; j < RY; j++) lds[0][L.lown[j]] = q[j][M];
+#pragma unroll
+        for (int k = 0; k < NHK; k++) {
+            const float4 h = buf_ld4(make_rsrc(pc, plane_bytes), L.hgoff[k]);
+            if (L.hloff[k] >= 0) lds[0][L.hloff[k]] = h;
+        }
+    }
     if constexpr (RP > 0) {
-        // ring slot i: halo of plane zs+i; the halo of plane zs+M+PF-1 is in flight like the one every step fetches
+        // ring slot i: halo of plane zs+H0+i; the halo of plane zs+H0+RP is in flight like the one every step fetches
 #pragma unroll
         for (int i = 0; i < RP; i++)
 #pragma unroll
             for (int k = 0; k < NHK; k++) {
                 const int hidx = t + k * NT;
                 ring[(k < NHK - 1 || hidx < NHQ) ? i * NHQ + hidx : RP * NHQ + hidx - NHQ] =
-                    buf_ld4(make_rsrc(pc + (long long)i * p.plane, (zs + i < ze) ? plane_bytes : 0u), L.hgoff[k]);
+                    buf_ld4(make_rsrc(pc + (long long)(H0 + i) * p.plane, (zs + H0 + i < ze) ? plane_bytes : 0u), L.hgoff[k]);
             }
 #pragma unroll
         for (int k = 0; k < NHK; k++)
-            hv[k] = buf_ld4(make_rsrc(pc + (long long)RP * p.plane, (zs + RP < ze) ? plane_bytes : 0u), L.hgoff[k]);
+            hv[k] = buf_ld4(make_rsrc(pc + (long long)(H0 + RP) * p.plane, (zs + H0 + RP < ze) ? plane_bytes : 0u), L.hgoff[k]);
     } else {
 #pragma unroll
-        for (int k = 0; k < NHK; k++) hv[k] = buf_ld4(make_rsrc(pc, plane_bytes), L.hgoff[k]);
+        for (int k = 0; k < NHK; k++) hv[k] = buf_ld4(make_rsrc(pc + (long long)H0 * p.plane, (zs + H0 < ze) ? plane_bytes : 0u), L.hgoff[k]);
     }
     const bool strip = !is_composite(ORDER) && p.shell != nullptr;  // uniform
     const long long ep = strip ? p.shell_plane : 0;
@@ -490,7 +530,8 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
     while (z < ze) {
         unroll_phases<0, QT>([&](auto ph) {
             if (z < ze) {
-                plane_step<M, TQ, LY, RY, ORDER, PF, decltype(ph)::value>(q, eo, hv, L, lds[par], ring, rslot, pn, pc, po, pe, ep, z < zn_end, z + 1 < ze, z + M + PF < ze,
+                plane_step<M, TQ, LY, RY, ORDER, PF, decltype(ph)::value>(q, eo, hv, L, lds[par], lds[par ^ 1], ring, rslot, pn, pc, po, pe, ep, z < zn_end, z + 1 < ze,
+                                                                        z + 2 < ze, z + M + PF < ze,
                                                                         plane_bytes, c, cs, p.zg0 + z);
                 par ^= 1;
 #ifdef FDTDX_DRIFT_PROBE
