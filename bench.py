@@ -655,6 +655,8 @@ def main():
                     + (f"cut into {world} z-slabs" if fixed else f"z-slabs of {a.n} planes per GPU"))
         if a.variant == "config3":
             workload = ("fdtd1..fdtd8 (star radius 1..8, fdtd1.cu .. fdtd8.cu) each timed on this grid; value = the slowest, " + workload)
+    # with the drivers' coefficients the field grows by 0.01 + 0.27 M per step: from radius 5 up every value is inf after this many steps
+    overflow_after = {5: 290, 6: 183, 7: 139, 8: 115}.get(r["radius"]) if r["kind"] == "star" else None
     line = {
         "metric": "cell-updates/sec", "value": t["gcells"], "unit": "Gcell/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": t["ms_per_step"],
@@ -667,6 +669,10 @@ def main():
                      "launch_us": t["launch_us"], "launches": t["launches"], "launch_us_source": t["launch_us_source"],
                      "traffic_source": t["traffic_source"]},
     }
+    if overflow_after:
+        line["config"]["values"] = (f"finite throughout the timed steps" if a.steps + a.warmup <= overflow_after else
+                                    f"overflow to inf after about {overflow_after} steps (fdtd{r['radius']}.cu's coefficients): most timed sweeps run on "
+                                    f"infinities, which is up to 8 % faster than on finite numbers (higher clock); --steps 20 times finite fields")
     if len(names) > 1:
         line["variants"] = table
     if a.all_variants and world == 1 and a.variant != "config3":
