@@ -176,6 +176,7 @@ extern "C" int fdtdx_destroy(fdtdx_ctx *ctx)
     for (auto &kv : ctx->pool)
         if (kv.second.owned && kv.second.ptr && hipFree(kv.second.ptr) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(%s) failed", kv.first.c_str());
     if (ctx->tb_scratch && hipFree(ctx->tb_scratch) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(scratch) failed");
+    if (ctx->stage && hipFree(ctx->stage) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(staging) failed");
     if (ctx->saved_sum && hipFree(ctx->saved_sum) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(saved) failed");
     for (int i = 0; i < 2; i++)
         if (ctx->shell_strip[i] && hipFree(ctx->shell_strip[i]) != hipSuccess) rc = fail(FDTDX_ERR_HIP, "hipFree(shell strip) failed");
@@ -264,13 +265,43 @@ extern "C" int fdtdx_get_cube(fdtdx_ctx *ctx, const char *name, float **device_p
     return fdtdx_find_cube(ctx, name, device_ptr);
 }
 
-// ---- transfers (stencil.h:596-637): pitch conversion done by the copy engine -------------------
+// ---- transfers (stencil.h:596-637): pitch conversion on the device ----------------------------------
+// The unpadded planes cross PCIe as flat copies into (out of) a staging buffer on the device, and a device-to-device 2-D copy
+// pads (unpads) them there.  (A 2-D copy straight between pageable host memory and the padded cube moves row by row: 0.2-0.3
+// GB/s measured for the 2 KB rows of a 512^3 cube, 2.4 s per cube.)  The staging buffer belongs to the context (at most 256 MB,
+// allocated on first use); without it the direct 2-D copy is used.  All copies go through the null stream, in order.
+static uint64_t stage_planes(fdtdx_ctx *ctx, uint64_t nplanes)
+{
+    const uint64_t per_plane = ctx->cfg.X * ctx->cfg.Y;
+    const uint64_t want = std::max<uint64_t>(1, std::min<uint64_t>(nplanes, (256ull << 20) / (per_plane * sizeof(float))));
+    if (ctx->stage_floats < want * per_plane) {
+        if (ctx->stage) (void)hipFree(ctx->stage);
+        ctx->stage = nullptr, ctx->stage_floats = 0;
+        if (hipMalloc((void **)&ctx->stage, want * per_plane * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->stage = nullptr;
+            return 0;
+        }
+        ctx->stage_floats = want * per_plane;
+    }
+    return ctx->stage_floats / per_plane;
+}
+
 static int copy_planes_h2d(fdtdx_ctx *ctx, float *dev, const float *host, uint64_t nplanes)
 {
     USE_DEVICE(ctx);
     const fdtdx_geometry &g = ctx->g;
     const uint64_t X = ctx->cfg.X, Y = ctx->cfg.Y;
-    HIP_TRY(hipMemcpy2D(dev, g.pitch_x * sizeof(float), host, X * sizeof(float), X * sizeof(float), nplanes * Y, hipMemcpyHostToDevice));
+    const uint64_t batch = stage_planes(ctx, nplanes);
+    if (!batch) {
+        HIP_TRY(hipMemcpy2D(dev, g.pitch_x * sizeof(float), host, X * sizeof(float), X * sizeof(float), nplanes * Y, hipMemcpyHostToDevice));
+        return FDTDX_OK;
+    }
+    for (uint64_t z = 0; z < nplanes; z += batch) {
+        const uint64_t n = std::min(batch, nplanes - z);
+        HIP_TRY(hipMemcpy(ctx->stage, host + z * Y * X, n * Y * X * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy2D(dev + z * g.plane, g.pitch_x * sizeof(float), ctx->stage, X * sizeof(float), X * sizeof(float), n * Y, hipMemcpyDeviceToDevice));
+    }
     return FDTDX_OK;
 }
 int fdtdx_copy_planes_d2h(fdtdx_ctx *ctx, float *host, const float *dev, uint64_t nplanes);
@@ -283,7 +314,16 @@ int fdtdx_copy_planes_d2h(fdtdx_ctx *ctx, float *host, const float *dev, uint64_
     HIP_TRY(hipDeviceSynchronize());
     const fdtdx_geometry &g = ctx->g;
     const uint64_t X = ctx->cfg.X, Y = ctx->cfg.Y;
-    HIP_TRY(hipMemcpy2D(host, X * sizeof(float), dev, g.pitch_x * sizeof(float), X * sizeof(float), nplanes * Y, hipMemcpyDeviceToHost));
+    const uint64_t batch = stage_planes(ctx, nplanes);
+    if (!batch) {
+        HIP_TRY(hipMemcpy2D(host, X * sizeof(float), dev, g.pitch_x * sizeof(float), X * sizeof(float), nplanes * Y, hipMemcpyDeviceToHost));
+        return FDTDX_OK;
+    }
+    for (uint64_t z = 0; z < nplanes; z += batch) {
+        const uint64_t n = std::min(batch, nplanes - z);
+        HIP_TRY(hipMemcpy2D(ctx->stage, X * sizeof(float), dev + z * g.plane, g.pitch_x * sizeof(float), X * sizeof(float), n * Y, hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemcpy(host + z * Y * X, ctx->stage, n * Y * X * sizeof(float), hipMemcpyDeviceToHost));
+    }
     return FDTDX_OK;
 }
 
@@ -338,7 +378,7 @@ extern "C" int fdtdx_init_mt(fdtdx_ctx *ctx, const char *name_p0, const char *na
     const fdtdx_geometry &g = ctx->g;
     const uint64_t X = ctx->cfg.X, Y = ctx->cfg.Y;
     // stage a bounded number of planes at a time so host memory stays small for big slabs
-    const uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(g.local_planes, (256ull << 20) / (Y * X * sizeof(float)) + 1));
+    const uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(g.local_planes, (256ull << 20) / (Y * X * sizeof(float))));
     std::vector<float> h0(batch * Y * X), h1(batch * Y * X);
     for (uint64_t zb = 0; zb < g.local_planes; zb += batch) {
         const uint64_t n = std::min(batch, g.local_planes - zb);
@@ -359,8 +399,8 @@ extern "C" int fdtdx_init_mt(fdtdx_ctx *ctx, const char *name_p0, const char *na
                 for (uint64_t zi = w; zi < n; zi += nthr) fill(zi);
             });
         for (auto &th : pool) th.join();
-        HIP_TRY(hipMemcpy2D(d0 + zb * g.plane, g.pitch_x * 4, h0.data(), X * 4, X * 4, n * Y, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy2D(d1 + zb * g.plane, g.pitch_x * 4, h1.data(), X * 4, X * 4, n * Y, hipMemcpyHostToDevice));
+        if ((rc = copy_planes_h2d(ctx, d0 + zb * g.plane, h0.data(), n))) return rc;
+        if ((rc = copy_planes_h2d(ctx, d1 + zb * g.plane, h1.data(), n))) return rc;
     }
     return FDTDX_OK;
 }
@@ -373,13 +413,17 @@ extern "C" int fdtdx_init_jacobi(fdtdx_ctx *ctx, const char *name)
     USE_DEVICE(ctx);
     const fdtdx_geometry &g = ctx->g;
     const uint64_t X = ctx->cfg.X, Y = ctx->cfg.Y;
-    std::vector<float> h(Y * X);
-    for (uint64_t z = 0; z < g.local_planes; z++) {
-        const uint64_t k = g.first_global + z;
-        for (uint64_t j = 0; j < Y; j++)
-            for (uint64_t i = 0; i < X; i++)  // jacobi.cu:415: i - j + 1.0/(k+1) in double
-                h[j * X + i] = (float)((double)((long long)i - (long long)j) + 1.0 / (double)(k + 1));
-        HIP_TRY(hipMemcpy2D(d + z * g.plane, g.pitch_x * 4, h.data(), X * 4, X * 4, Y, hipMemcpyHostToDevice));
+    const uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(g.local_planes, (64ull << 20) / (Y * X * sizeof(float))));
+    std::vector<float> h(batch * Y * X);
+    for (uint64_t zb = 0; zb < g.local_planes; zb += batch) {
+        const uint64_t n = std::min(batch, g.local_planes - zb);
+        for (uint64_t z = 0; z < n; z++) {
+            const uint64_t k = g.first_global + zb + z;
+            for (uint64_t j = 0; j < Y; j++)
+                for (uint64_t i = 0; i < X; i++)  // jacobi.cu:415: i - j + 1.0/(k+1) in double
+                    h[(z * Y + j) * X + i] = (float)((double)((long long)i - (long long)j) + 1.0 / (double)(k + 1));
+        }
+        if ((rc = copy_planes_h2d(ctx, d + zb * g.plane, h.data(), n))) return rc;
     }
     return FDTDX_OK;
 }
