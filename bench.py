@@ -187,7 +187,7 @@ def main():
     ap.add_argument("--no-standing-start", dest="standing_start", action="store_false",
                     help="skip the extra 1000-step run from a standing start (one rank, sweep variants)")
     ap.add_argument("--all-variants", action="store_true", help="also time every other variant (N=1 only)")
-    ap.add_argument("--exchange", default="native", choices=["native", "ipc", "torch"],
+    ap.add_argument("--exchange", default="ipc", choices=["native", "ipc", "torch"],
                     help="N > 1: who moves the ghost planes -- native: the library's own RCCL send/recv on its exchange stream "
                          "(fdtdx_run); ipc: the library's copy transport (neighbours' cubes mapped between the processes, planes pushed by "
                          "device copies, no exchange kernel on any CU; falls back to native); torch: torch.distributed P2P ops issued "
@@ -356,7 +356,7 @@ def main():
         for i, name in enumerate(names):
             be.alloc(name).uniform_(0.0, 1.0, generator=torch.Generator(device=be.device).manual_seed(6 * rank + i))
         mode = "host" if a.rehearse_shared_gpu else "device"
-        if a.exchange == "native" and not a.rehearse_shared_gpu:
+        if a.exchange in ("native", "ipc") and not a.rehearse_shared_gpu:  # (the copy transport moves whole ghost blocks of one cube: not these half steps)
             # the library's own communicator, as for the sweeps; every rank takes the same path
             ok = torch.ones(1, device="cuda")
             box = [None]
@@ -499,6 +499,53 @@ def main():
             if ok.item() == 0:
                 native = False
                 a.exchange = "torch"
+
+        if native or use_ipc:
+            # Before anything is timed: does the transport deliver?  Every rank writes numbers that name it, the side and the plane
+            # into the planes its neighbours are due, exchanges once through the library and looks at what arrived in its ghost
+            # planes; the planes are then put back.  All ranks agree on the outcome; a transport that fails is replaced by the next.
+            g = be.g
+            glo, ghi, L = int(g.ghost_lo), int(g.ghost_hi), int(g.local_planes)
+            regions = [(0, glo), (glo, ghost), (L - ghi - ghost, ghost), (L - ghi, ghi)]
+            saved = [be.planes("p0", z0, cnt).clone() for z0, cnt in regions]
+            pl = int(g.plane)
+
+            def pattern(r, side, cnt):
+                return (torch.arange(cnt, device="cuda", dtype=torch.float32) + (1000.0 * r + 100.0 * side)).repeat_interleave(pl)
+
+            ok = torch.ones(1, device=flag_dev)
+            try:
+                if glo:
+                    be.planes("p0", glo, ghost).copy_(pattern(rank, 0, ghost))
+                if ghi:
+                    be.planes("p0", L - ghi - ghost, ghost).copy_(pattern(rank, 1, ghost))
+                torch.cuda.synchronize()
+                be.st.commCubeHalo("p0", cs)
+                torch.cuda.synchronize()
+                if glo and not torch.equal(be.planes("p0", 0, glo), pattern(rank - 1, 1, glo)):
+                    raise RuntimeError("the ghost planes below do not hold what the neighbour below sent")
+                if ghi and not torch.equal(be.planes("p0", L - ghi, ghi), pattern(rank + 1, 0, ghi)):
+                    raise RuntimeError("the ghost planes above do not hold what the neighbour above sent")
+                if os.environ.get("FDTDX_BENCH_FAIL_PROBE") == a.exchange and rank == world - 1:
+                    raise RuntimeError("failure asked for (FDTDX_BENCH_FAIL_PROBE), to rehearse the fallback")
+            except Exception as e:
+                print(f"rank {rank}: exchange probe failed over {a.exchange} ({e})", file=sys.stderr)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            dist.barrier()
+            torch.cuda.synchronize()
+            for (z0, cnt), t in zip(regions, saved):
+                if cnt:
+                    be.planes("p0", z0, cnt).copy_(t)
+            torch.cuda.synchronize()
+            dist.barrier()
+            del saved
+            if ok.item() == 0:
+                be.st.close()  # the communicator goes with the context
+                del be, run
+                torch.cuda.empty_cache()
+                a.exchange = "native" if a.exchange == "ipc" else "torch"
+                return time_variant(name, steps, warmup)
 
         def loop(k):
             if world == 1:
@@ -699,7 +746,7 @@ def main():
         dist.all_gather_object(who, {"rank": rank, "device": local_rank, "name": torch.cuda.get_device_name(local_rank)})
         line["ranks"] = who
         line["config"]["exchange"] = ("host-staged gloo (rehearsal)" if (a.rehearse_shared_gpu and a.exchange != "ipc") else
-                                      "device copies into the neighbours' mapped cubes (IPC), issued by the library on its exchange stream, hosts pacing" if a.exchange == "ipc" else
+                                      "device copies into the neighbours' mapped cubes (IPC), issued by the library on one copy stream per direction, hosts pacing; checked by a probe exchange before the timed steps" if a.exchange == "ipc" else
                                       "RCCL send/recv issued by the library on its exchange stream" if (a.exchange == "native" and r.get("exchange", "native") == "native")
                                       else "torch.distributed batch_isend_irecv on the nccl (= RCCL) backend")
         line["config"]["world_size"] = dist.get_world_size()

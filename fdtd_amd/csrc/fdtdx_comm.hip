@@ -111,6 +111,7 @@ struct IpcShared {
 struct fdtdx_comm {
     int mode = COMM_LOCAL;
     hipStream_t xs = nullptr;       // the exchange stream
+    hipStream_t xs2 = nullptr;      // IPC: the copy towards the neighbour above (the two directions use different links and copy engines)
     hipStream_t bs = nullptr;       // the boundary stream: a step's boundary-plane sweeps, beside its interior sweep
     hipEvent_t fork = nullptr;      // recorded on the caller's stream when a step begins: what the boundary sweeps wait for
     hipEvent_t ready = nullptr;     // recorded on the caller's stream: the boundary planes of this step are written
@@ -161,6 +162,7 @@ static int comm_streams(fdtdx_ctx *ctx, fdtdx_comm *c)
         HIP_TRY(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
     }
     HIP_TRY(hipStreamCreateWithFlags(&c->bs, hipStreamNonBlocking));
+    if (c->mode == COMM_IPC) HIP_TRY(hipStreamCreateWithFlags(&c->xs2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
@@ -176,6 +178,7 @@ void fdtdx_comm_release(fdtdx_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (c->bs) (void)hipStreamSynchronize(c->bs);
     if (c->xs) (void)hipStreamSynchronize(c->xs);
+    if (c->xs2) (void)hipStreamSynchronize(c->xs2);
     if (c->comm) {
         RcclApi *api = nullptr;
         if (rccl(&api) == FDTDX_OK) (void)api->CommDestroy(c->comm);
@@ -187,6 +190,7 @@ void fdtdx_comm_release(fdtdx_ctx *ctx)
     if (c->fork) (void)hipEventDestroy(c->fork);
     if (c->bs) (void)hipStreamDestroy(c->bs);
     if (c->xs) (void)hipStreamDestroy(c->xs);
+    if (c->xs2) (void)hipStreamDestroy(c->xs2);
     if (c->token) (void)hipFree(c->token);
     for (void *p : c->opened) (void)hipIpcCloseMemHandle(p);
     for (int s = 0; s < 2; s++)
@@ -225,7 +229,7 @@ extern "C" int fdtdx_comm_state(fdtdx_ctx *ctx, char *buf, size_t len)
         return r == hipSuccess ? "idle" : r == hipErrorNotReady ? "BUSY" : "error";
     };
     snprintf(buf, len, "rank %u mode=%s epoch=%llu waited=%llu | events: fork=%s ready=%s done=%s guard_lo=%s guard_hi=%s | streams: exchange=%s boundary=%s caller(last)=%s",
-             ctx->cfg.rank, c->mode == COMM_RCCL ? "rccl" : "local", (unsigned long long)c->epoch, (unsigned long long)c->waited, ev(c->fork), ev(c->ready),
+             ctx->cfg.rank, c->mode == COMM_RCCL ? "rccl" : c->mode == COMM_IPC ? "ipc" : "local", (unsigned long long)c->epoch, (unsigned long long)c->waited, ev(c->fork), ev(c->ready),
              ev(c->done), ev(c->guard[0]), ev(c->guard[1]), st(c->xs), st(c->bs), st(c->last_stream));
     return FDTDX_OK;
 }
@@ -482,6 +486,7 @@ extern "C" int fdtdx_comm_exchange_start(fdtdx_ctx *ctx, const char *name, void 
     }
     c->marked = false;
     HIP_TRY(hipStreamWaitEvent(c->xs, c->ready, 0));
+    if (c->xs2) HIP_TRY(hipStreamWaitEvent(c->xs2, c->ready, 0));
     if (c->mode == COMM_RCCL) {
         RcclApi *api;
         if ((rc = rccl(&api))) return rc;
@@ -505,7 +510,7 @@ extern "C" int fdtdx_comm_exchange_start(fdtdx_ctx *ctx, const char *name, void 
         // push: this rank's boundary planes into the neighbour's ghost planes on the side that faces this rank.  What the
         // copy overwrites there the neighbour last read in the boundary sweep of its previous step, and that sweep had
         // finished before the neighbour pushed the planes this rank's own boundary sweep (queued ahead of this copy) has
-        // just read: nothing more to wait for.
+        // just read: nothing more to wait for.  One stream per direction: the two copies leave over different links.
         for (int s = 0; s < 2; s++) {
             if (!cnt[s]) continue;
             auto it = c->peer_cube[s].find(name);
@@ -514,8 +519,9 @@ extern "C" int fdtdx_comm_exchange_start(fdtdx_ctx *ctx, const char *name, void 
             const uint64_t depth = s ? pg.ghost_lo : pg.ghost_hi;  // its ghost planes towards this rank
             if (depth * pg.plane != cnt[s]) return fail(FDTDX_ERR_INVALID, "the neighbouring slab has another geometry");
             float *dst = it->second + (s ? 0 : (pg.local_planes - pg.ghost_hi) * pg.plane);
-            HIP_TRY(hipMemcpyAsync(dst, snd[s], cnt[s] * sizeof(float), hipMemcpyDeviceToDevice, c->xs));
+            HIP_TRY(hipMemcpyAsync(dst, snd[s], cnt[s] * sizeof(float), hipMemcpyDeviceToDevice, s ? c->xs2 : c->xs));
         }
+        submit_now(c->xs2);
     } else {
         for (int s = 0; s < 2; s++) {
             fdtdx_ctx *o = c->nb[s];
@@ -562,9 +568,10 @@ extern "C" int fdtdx_comm_exchange_wait(fdtdx_ctx *ctx, void *stream)
         // the hosts pace the exchange: this rank's copies have landed (it says so), then its neighbours' (they say so);
         // what the caller queues after this call is queued after both
         if (c->broken) return fail(FDTDX_ERR_HIP, "an earlier exchange of this communicator failed");
-        HIP_TRY(hipStreamSynchronize(c->xs));
-        for (int s = 0; s < 2; s++)
+        for (int s = 0; s < 2; s++) {
+            HIP_TRY(hipStreamSynchronize(s ? c->xs2 : c->xs));
             if (c->peer_sh[s]) c->self_sh->landed[s].store(c->epoch, std::memory_order_release);
+        }
         for (int s = 0; s < 2; s++)
             if (c->peer_sh[s] && !ipc_await(c->peer_sh[s]->landed[1 - s], c->epoch, 60.0)) {
                 c->broken = true;
