@@ -82,17 +82,36 @@ constexpr int star_nhk(int M, int TQ, int LY, int RY)
 #ifndef FDTDX_ABLATE
 #define FDTDX_ABLATE 0
 #endif
-// 1: a step publishes the NEXT centre plane to LDS after its own arithmetic, behind one barrier at the top of the step; 0: it
-// publishes its own centre plane first and meets the barrier before the arithmetic.  The LDS stores of a publish are slow
-// (a 16-byte store takes about 13 cycles to move from the registers, three times a 16-byte read) and nothing of the same wave
-// overlaps them when the barrier follows at once; behind the arithmetic they overlap other waves' reads and multiplies.
-// Measured at 512^3 on fields that stay finite: radius 7 gains 5 % (226 -> 215 us per sweep), radius 6 is level, radius 3-5
-// lose 2-6 % (their halo loads move behind the arithmetic with the publish) and radius 8 does not fit its 128 registers in
-// this order (101 spilled; 268 us with the default scheduler against 249).  So it is a per-radius choice: a translation
-// unit that wants it defines FDTDX_LATE_PUBLISH 1 before it includes this header (star_m7.hip).
+// Late publish: a step publishes the NEXT centre plane to LDS after its own arithmetic, behind one barrier at the top of the
+// step; otherwise it publishes its own centre plane first and meets the barrier before the arithmetic.  The LDS stores of a
+// publish are slow (a 16-byte store takes about 13 cycles to move from the registers, three times a 16-byte read) and nothing of
+// the same wave overlaps them when the barrier follows at once; behind the arithmetic they overlap other waves' reads and
+// multiplies.  Measured at 512^3 on fields that stay finite, 32 x 32-quad tiles: radius 7 gains 5 % (226 -> 215 us per sweep),
+// radius 8 2-4 % (241 -> 232-236; it fits its 128 registers in this order only together with the same-step fetch below: 101
+// registers spilled without), radius 6 is level, radius 3-5 lose 2-6 % (their halo loads move behind the arithmetic with the
+// publish).  Fetching the halo at the top of the step instead of its end was measured too: level at radius 7-8, 6-11 % slower
+// at radius 3, 4 and 6.  So it is a per-instantiation choice (star_late).
+// Same-step fetch: the shell components of a partly stored quad of the output are fetched by the step that stores it (as the
+// step's first load, so that waiting for it waits for nothing else) instead of one step ahead: four registers fewer per row, no
+// difference in time by itself (radius 6-8).  Not for the composite update, which reads the old output of every cell.
+// FDTDX_LATE_PUBLISH / FDTDX_EO_SAME_STEP = 0 or 1 force either for every kernel of a translation unit (experiments).
 #ifndef FDTDX_LATE_PUBLISH
-#define FDTDX_LATE_PUBLISH 0
+#define FDTDX_LATE_PUBLISH -1
 #endif
+#ifndef FDTDX_EO_SAME_STEP
+#define FDTDX_EO_SAME_STEP -1
+#endif
+constexpr bool star_late(int M, int TQ, int LY, int RY, int ORDER)
+{
+    if (FDTDX_LATE_PUBLISH >= 0) return FDTDX_LATE_PUBLISH != 0;
+    return ORDER == ORD_STAR_CHAIN && (M == 7 || M == 8) && TQ == 32 && LY == 32 && RY == 1;
+}
+constexpr bool star_eo_same_step(int M, int TQ, int LY, int RY, int ORDER)
+{
+    if (is_composite(ORDER)) return false;
+    if (FDTDX_EO_SAME_STEP >= 0) return FDTDX_EO_SAME_STEP != 0;
+    return star_late(M, TQ, LY, RY, ORDER);
+}
 // quads of a ring of `planes` planes: the halo quads of each plane, and one spare quad for every thread that has no halo
 // quad in its last round (it parks the zeros its masked load returns there, so that the ring traffic needs no branch)
 constexpr int star_ring_quads(int M, int TQ, int LY, int RY, int planes)
@@ -102,11 +121,11 @@ constexpr int star_ring_quads(int M, int TQ, int LY, int RY, int planes)
 constexpr int star_ring_planes(int M, int TQ, int LY, int RY, int ORDER, int PF)
 {
     const int images = 2 * (LY * RY + 2 * M) * (TQ + 2 * ((M + 3) / 4)) * 16;
-    const int ring = star_ring_quads(M, TQ, LY, RY, M + PF - 1 - FDTDX_LATE_PUBLISH) * 16;
+    const int ring = star_ring_quads(M, TQ, LY, RY, M + PF - 1 - (star_late(M, TQ, LY, RY, ORDER) ? 1 : 0)) * 16;
     // not in the separate-multiply-add order from radius 5 up: those kernels are bound by their arithmetic and registers, and
     // measured 1-10 % slower with the ring's extra LDS traffic (radius 3: 7 % faster, radius 4: level)
     if (ORDER == ORD_STAR_GOLDEN && M >= 5) return 0;
-    return (M >= FDTDX_RING_MIN_M && !is_composite(ORDER) && images + ring <= 160 * 1024) ? M + PF - 1 - FDTDX_LATE_PUBLISH : 0;
+    return (M >= FDTDX_RING_MIN_M && !is_composite(ORDER) && images + ring <= 160 * 1024) ? M + PF - 1 - (star_late(M, TQ, LY, RY, ORDER) ? 1 : 0) : 0;
 }
 
 // Per-thread constants of the march.
@@ -179,7 +198,8 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
                 if (L.hloff[k] >= 0) dst[L.hloff[k]] = hv[k];
         }
     };
-    if constexpr (FDTDX_LATE_PUBLISH) {
+    constexpr bool LATE = star_late(M, TQ, LY, RY, ORDER);
+    if constexpr (LATE) {
         // plane z is complete in `buf` (the step before, or the prologue, published it) and nobody reads `bufn` any more
         if constexpr (!(FDTDX_ABLATE & 32)) __syncthreads();
     } else {
@@ -191,15 +211,27 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
     const long long pf = plane_bytes >> 2;
     const __amdgpu_buffer_rsrc_t rn = make_rsrc(pn, nbn);        // plane z+M+PF
     // no ring: the halo of the plane the next publish needs -- plane z+1, or (late publish, which works a step ahead) z+2
-    const __amdgpu_buffer_rsrc_t rc = FDTDX_LATE_PUBLISH ? make_rsrc(pc + 2 * pf, more_c2 ? plane_bytes : 0u) : make_rsrc(pc + pf, nbc);
+    const __amdgpu_buffer_rsrc_t rc = LATE ? make_rsrc(pc + 2 * pf, more_c2 ? plane_bytes : 0u) : make_rsrc(pc + pf, nbc);
     // shell components of output plane z+1: from the output cube, or from the strip kept beside it
     const __amdgpu_buffer_rsrc_t ron = pe ? make_rsrc(pe + ep, more_c ? (unsigned)(ep * 4) : 0u) : make_rsrc(po + pf, nbc);
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(po, plane_bytes);
+    auto load_halo = [&]() {
+        if constexpr (!(FDTDX_ABLATE & 4)) {
+            // ring: the halo of the plane the own quads are fetched of (only planes that become a centre plane of this chunk need
+            // one); no ring: the halo of the next plane to be published
+#pragma unroll
+            for (int k = 0; k < NHK; k++) hv[k] = RP > 0 ? buf_ld4(rn, more_h ? L.hgoff[k] : OOB) : buf_ld4(rc, L.hgoff[k]);
+        }
+    };
     float4 eo_cur[RY], vq_cur[RY], sq_cur[RY];
     const bool fuse_mul = is_composite(ORDER) && cs.ps != nullptr;  // uniform
+    constexpr bool EO_NOW = star_eo_same_step(M, TQ, LY, RY, ORDER);
 #pragma unroll
     for (int j = 0; j < RY; j++) {
-        eo_cur[j] = eo[j];
+        if constexpr (EO_NOW)  // ahead of the other loads: loads complete in the order of issue, and this one the step itself waits for
+            eo_cur[j] = buf_ld4(pe ? make_rsrc(pe, (unsigned)(ep * 4)) : ro, L.eoff[j]);
+        else
+            eo_cur[j] = eo[j];
         q[j][QS(QT - 1)] = buf_ld4(rn, L.goff[j]);
     }
     if constexpr (is_composite(ORDER)) {  // the second input of plane z+1, for the cells this thread computes
@@ -213,21 +245,13 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
             cs.sq[j] = buf_ld4s(rs, L.soff[j]);
         }
     }
-    auto load_halo = [&]() {
-        if constexpr (!(FDTDX_ABLATE & 4)) {
-            // ring: the halo of the plane the own quads are fetched of (only planes that become a centre plane of this chunk need
-            // one); no ring: the halo of the next plane to be published
-#pragma unroll
-            for (int k = 0; k < NHK; k++) hv[k] = RP > 0 ? buf_ld4(rn, more_h ? L.hgoff[k] : OOB) : buf_ld4(rc, L.hgoff[k]);
-        }
-    };
-    if constexpr (!FDTDX_LATE_PUBLISH) load_halo();
-    if constexpr (!(FDTDX_ABLATE & 8)) {
+    if constexpr (!LATE) load_halo();
+    if constexpr (!(FDTDX_ABLATE & 8) && !EO_NOW) {
 #pragma unroll
         for (int j = 0; j < RY; j++)  // streamed past the caches where measured faster: full-row tiles (+2-4 % at radius 1 and 3; 3 % slower with x tiles)
             eo[j] = (is_composite(ORDER) || TQ >= 128) ? buf_ld4s(ron, L.eoff[j]) : buf_ld4(ron, L.eoff[j]);
     }
-    if constexpr (!FDTDX_LATE_PUBLISH && !(FDTDX_ABLATE & 32)) __syncthreads();
+    if constexpr (!LATE && !(FDTDX_ABLATE & 32)) __syncthreads();
 
     const float c0 = c[0], cxp = c[1], cxm = c[2], cyp = c[3], cym = c[4], czp = c[5], czm = c[6];
 #pragma unroll
@@ -356,7 +380,7 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
         buf_st4(ro, (FDTDX_ABLATE & 16) ? (__float_as_uint(acc[0] + acc[1] + acc[2] + acc[3]) == 0x7fc12345u ? L.soff[j] : OOB) : L.soff[j],
                 L.m0 ? acc[0] : eo_cur[j].x, L.m1 ? acc[1] : eo_cur[j].y, L.m2 ? acc[2] : eo_cur[j].z, L.m3 ? acc[3] : eo_cur[j].w);
     }
-    if constexpr (FDTDX_LATE_PUBLISH) {
+    if constexpr (LATE) {
         publish(bufn, QS(M + 1));  // plane z+1: the next step's centre plane (its halo: from the ring, or fetched by the step before)
         load_halo();
     }
@@ -469,8 +493,9 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
     const float *pc = p.in + (long long)zs * p.plane;  // centre plane
     float *po = p.out + (long long)zs * p.plane;
     // late publish: the first centre plane and its halo go to LDS here; everything after it is one plane further on
-    constexpr int H0 = FDTDX_LATE_PUBLISH;  // first plane (counted from zs) whose halo a step of the loop publishes
-    if constexpr (FDTDX_LATE_PUBLISH) {
+    constexpr bool LATE = star_late(M, TQ, LY, RY, ORDER);
+    constexpr int H0 = LATE ? 1 : 0;  // first plane (counted from zs) whose halo a step of the loop publishes
+    if constexpr (LATE) {
 #pragma unroll
         for (int j = 0; j < RY; j++) lds[0][L.lown[j]] = q[j][M];
 #pragma unroll
