@@ -186,6 +186,9 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
 #pragma unroll
             for (int k = 0; k < NHK; k++) {
                 const int hidx = (int)threadIdx.x + k * NT;
+                // a wave whose lanes all lie past the last halo quad has none in this round and skips the ring (radius 8, 32 x 32
+                // quads: 6 of 16 waves, 2.5 % of the sweep's time; radius 7: 1 %)
+                if (k == NHK - 1 && __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) * 64 + k * NT >= NHQ) continue;
                 float4 *rs = ring + ((k < NHK - 1 || hidx < NHQ) ? rslot * NHQ + hidx : RP * NHQ + hidx - NHQ);
                 const float4 h = *rs;
                 *rs = hv[k];
