@@ -88,7 +88,8 @@ constexpr int star_nhk(int M, int TQ, int LY, int RY)
 // the same wave overlaps them when the barrier follows at once; behind the arithmetic they overlap other waves' reads and
 // multiplies.  Measured at 512^3 on fields that stay finite, 32 x 32-quad tiles: radius 7 gains 5 % (226 -> 215 us per sweep),
 // radius 8 2-4 % (241 -> 232-236; it fits its 128 registers in this order only together with the same-step fetch below: 101
-// registers spilled without), radius 6 is level, radius 3-5 lose 2-6 % (their halo loads move behind the arithmetic with the
+// registers spilled without), radius 6 is level (its default shape, two rows per lane on 512 lanes: level over 100 steps, 2 % slower over the
+// first 20), radius 3-5 lose 2-6 % (their halo loads move behind the arithmetic with the
 // publish).  Fetching the halo at the top of the step instead of its end was measured too: level at radius 7-8, 6-11 % slower
 // at radius 3, 4 and 6.  So it is a per-instantiation choice (star_late).
 // Same-step fetch: the shell components of a partly stored quad of the output are fetched by the step that stores it (as the
