@@ -23,7 +23,7 @@ for spec in sys.argv[2:]:
     summ = json.loads(out)
     base = os.path.join(ROOT, "profiles", f"{rnd}_{variant}")
     json.dump(summ, open(base + "_summary.json", "w"), indent=1)
-    for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
+    for f in sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime):  # the newest one wins
         shutil.copy(f, base + "_kernel_stats.csv")
     try:  # the shape bench.py reported for the profiled run: bench.py drops the figure when the kernel's shape has changed since
         line = [l for l in open(os.path.join(src, "trace.log")) if l.startswith("{")][-1]

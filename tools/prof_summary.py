@@ -5,10 +5,25 @@ import collections
 import sys
 import json
 
+import os
+
 d = sys.argv[1]
 pat = sys.argv[2] if len(sys.argv) > 2 else "sweep"
 out = {}
-for f in glob.glob(f"{d}/trace/*/*_kernel_stats.csv"):
+
+
+def newest(pattern):
+    """One file per pass: gpurun merges a run's files into whatever an earlier run of the same tag left here (rocprofv3 names its files
+    after the process id), so only the newest file of each pass directory belongs to the last run."""
+    by_dir = {}
+    for f in glob.glob(pattern):
+        k = os.path.dirname(os.path.dirname(f))
+        if k not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[k]):
+            by_dir[k] = f
+    return sorted(by_dir.values())
+
+
+for f in newest(f"{d}/trace/*/*_kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         if pat in r["Name"]:
             out["kernel"] = r["Name"]
@@ -22,7 +37,7 @@ try:
     roof = json.loads(line)["roofline"]
     # the launches bench.py's launch_us is averaged over: its closing run of the dominant kernel
     timed = int(roof.get("launches") or max(6, min(60, int(json.loads(line)["steps"]) // max(1, round(roof["steps_per_launch"])))))
-    for f in glob.glob(f"{d}/trace/*/*_kernel_trace.csv"):
+    for f in newest(f"{d}/trace/*/*_kernel_trace.csv"):
         durs = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
                 for r in csv.DictReader(open(f)) if r["Kernel_Name"] == out.get("kernel")]
         durs.sort()
@@ -33,7 +48,7 @@ try:
             out["timed_avg_us"] = sum(last) / len(last) / 1e3
 except Exception as e:  # older runs without the line
     out["timed_avg_us"] = None
-for f in glob.glob(f"{d}/pmc_*/*/*_counter_collection.csv"):
+for f in newest(f"{d}/pmc_*/*/*_counter_collection.csv"):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if pat in r["Kernel_Name"]:
