@@ -1,3 +1,7 @@
+#!/usr/bin/env bash
+# tools/rehearse_shared_gpu.sh: the N > 1 paths of bench.py with two ranks on the box's one GPU (a rehearsal of the code paths, not a
+# measurement): the IPC and local-slab tests, one variant over the copy transport, the probe's fallback chain forced by
+# FDTDX_BENCH_FAIL_PROBE, and the whole default bench.  Results under gpurun_out/ (GPU box).
 set -o pipefail
 export MASTER_ADDR=127.0.0.1
 R="python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541"
