@@ -16,11 +16,11 @@ namespace fdtdx {
 
 __device__ __forceinline__ float lane_from_prev(float v)  // lane l receives lane l-1 (lane 0: lane 63)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xF, 0xF, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float lane_from_next(float v)  // lane l receives lane l+1 (lane 63: lane 0)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x134, 0xF, 0xF, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x134, 0xF, 0xF, true));
 }
 
 template <int TQ, int LY, int RY, int GOLDEN>

@@ -55,11 +55,11 @@ struct TbParams {
 
 __device__ __forceinline__ float dpp_from_prev_lane(float v)  // lane l receives lane l-1 (lane 0: lane 63)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xF, 0xF, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float dpp_from_next_lane(float v)  // lane l receives lane l+1 (lane 63: lane 0)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x134, 0xF, 0xF, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x134, 0xF, 0xF, true));
 }
 
 // one cell, in one of the reference's four summation orders

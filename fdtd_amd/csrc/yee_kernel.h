@@ -38,7 +38,7 @@ __device__ __forceinline__ void st4_stream(float *p, const float (&v)[4])
 
 __device__ __forceinline__ float dpp_prev_lane(float v)  // lane l receives lane l-1 (lane 0: lane 63)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xF, 0xF, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xF, 0xF, true));
 }
 
 __device__ __forceinline__ float upd(float a, float c, float d, int golden) { return golden ? a + c * d : __builtin_fmaf(c, d, a); }
