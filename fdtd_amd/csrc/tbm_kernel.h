@@ -51,10 +51,20 @@ __device__ __forceinline__ void star_rows(float4 (&res)[RY][RX], const float4 (&
             xs[M] = C.x, xs[M + 1] = C.y, xs[M + 2] = C.z, xs[M + 3] = C.w;
             // two cells per instruction (v_pk_mul/add/fma_f32), spelled out: cells 0,1 and 2,3 of the quad; per cell the same
             // operations in the same order as the scalar form
-#define XP(k) f32x2{xs[(k)], xs[(k) + 1]}
+            // a pair that starts on an odd component of a quad is one v_pk_mov_b32 away from the two register pairs it straddles
+            auto xpair = [&](auto kt) {
+                constexpr int k = decltype(kt)::value;
+                if constexpr (((k - M) & 1) == 0 || k - 1 < 0 || k + 2 >= 4 + 2 * M) {
+                    return f32x2{xs[k], xs[k + 1]};
+                } else {
+                    const f32x2 lo = {xs[k - 1], xs[k]}, hi = {xs[k + 1], xs[k + 2]};
+                    return __builtin_shufflevector(lo, hi, 1, 2);
+                }
+            };
+#define XP(k) xpair(PhaseTag<(k)>{})
             f32x2 a01 = c[0] * XP(M), a23 = c[0] * XP(M + 2);
-#pragma unroll
-            for (int r = 1; r <= M; r++) {
+            unroll_phases<1, M + 1>([&](auto rt) {
+                constexpr int r = decltype(rt)::value;
                 // rows t+r and t-r of the tile (t = w*RY + j): wave offset and row inside that wave are constants
                 constexpr int BIG = 64 * RY;
                 const int jp = j + r, jm = j - r;
@@ -77,7 +87,7 @@ __device__ __forceinline__ void star_rows(float4 (&res)[RY][RX], const float4 (&
                 a23 = term(a23, c[1], XP(M + 2 + r), c[2], XP(M + 2 - r));
                 a23 = term(a23, c[3], f32x2{Yp.z, Yp.w}, c[4], f32x2{Ym.z, Ym.w});
                 a23 = term(a23, c[5], f32x2{Zp.z, Zp.w}, c[6], f32x2{Zm.z, Zm.w});
-            }
+            });
 #undef XP
             const float a[4] = {a01.x, a01.y, a23.x, a23.y};
             res[j][i] = make_float4(a[0], a[1], a[2], a[3]);
