@@ -462,6 +462,8 @@ def main():
             dist.all_gather_object(descs, desc)
             if ok.item() != 0 and all(d is not None for d in descs):
                 try:
+                    if os.environ.get("FDTDX_BENCH_FAIL_CONNECT") and rank == world - 1:
+                        raise RuntimeError("failure asked for (FDTDX_BENCH_FAIL_CONNECT), to rehearse the fallback")
                     be.st.commIpcConnect(descs[rank - 1] if rank > 0 else None, descs[rank + 1] if rank < world - 1 else None)
                 except Exception as e:
                     print(f"rank {rank}: IPC connect failed ({e})", file=sys.stderr)
