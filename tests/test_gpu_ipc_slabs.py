@@ -18,7 +18,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
                                                         ("star", 1, 3, 2, 11, "fused3"), ("spc13", 1, 2, 3, 10, "fused2"),
                                                         ("star", 2, 4, 2, 9, "fused2")])
 def test_ipc_ranks_equal_undecomposed_loop(oracle_cpu, tmp_path, kind, R, ghost, n, steps, fused):
-    Z, Y, X = 24 * n + 2 * ghost, 41, 200
+    _run_ranks(oracle_cpu, tmp_path, kind, R, ghost, n, steps, fused, (24 * n + 2 * ghost, 41, 200))
+
+
+# the planes of the bench's own grid (512 x 512 cells, 1.1 MB each; ghost blocks of 3.3 and 8.9 MB per face and exchange)
+@pytest.mark.parametrize("kind,R,ghost,n,steps,fused", [("star", 8, 8, 2, 3, None), ("star", 1, 3, 2, 7, "fused3")])
+def test_ipc_ranks_full_size_planes(oracle_cpu, tmp_path, kind, R, ghost, n, steps, fused):
+    _run_ranks(oracle_cpu, tmp_path, kind, R, ghost, n, steps, fused, (192, 512, 512))
+
+
+def _run_ranks(oracle_cpu, tmp_path, kind, R, ghost, n, steps, fused, dims):
+    Z, Y, X = dims
     a, b = oracle_cpu.init_mt(Z, Y, X)
     np.save(tmp_path / "a.npy", a)
     np.save(tmp_path / "b.npy", b)
