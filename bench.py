@@ -181,6 +181,8 @@ def main():
     ap.add_argument("--order", default="chain", choices=["chain", "golden"],
                     help="arithmetic order of the sweeps: chain = the device lambdas' (every + c*v one FMA), golden = the host loops' "
                          "(separate IEEE multiplies and adds: the order the reference's compiled loops pin bit for bit)")
+    ap.add_argument("--shape", type=int, default=-1,
+                    help="tuning: index of the single-step kernel's tile shape among the compiled ones (tools/tune.py lists them); -1 = the library's choice")
     ap.add_argument("--fuse-wide", action="store_true",
                     help="one rank: run radius 3 and 4 through their two-step kernels (slower than single steps; kept for measurement)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -429,6 +431,8 @@ def main():
             be.st.initMt("p0", "p1")
         prog = make_program(kind, radius=radius, order=ORDER_GOLDEN if a.order == "golden" else ORDER_CHAIN)
         be.st.setOption("temporal", a.temporal)
+        if a.shape >= 0:
+            be.st.setOption("variant", a.shape)
         # the two-step loops that hop through a third cube (radius 2; radius 1 under --temporal 2) get it from here, by name:
         # nothing is allocated inside the timed loop
         work = None

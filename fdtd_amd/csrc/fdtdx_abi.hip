@@ -454,6 +454,12 @@ static void default_shape(int kind, int r, int nq, int *tq, int *ly, int *ry)
         *tq = 64, *ly = 8, *ry = 2;
         return;
     }
+    if (r == 3 && nq >= 128 && (nq % 64 == 0 || nq >= 512)) {
+        // 64 x 16 cells-quads on 512 lanes (two rows per lane, two workgroups per CU): 1.4 % ahead of full-row tiles at 512 cells per
+        // row, 3.5 % at 1024; rows that are not whole 64-quad tiles lose more to the ragged last tile (96 quads: 4 % behind)
+        *tq = 64, *ly = 8, *ry = 2;
+        return;
+    }
     if (r <= 4) {
         if (nq > 64)
             *tq = 128, *ly = 8, *ry = 1;
