@@ -657,7 +657,7 @@ static const TbVariantInfo *pick_tb(const fdtdx_ctx *ctx, const fdtdx_program *p
     int idx = 0;
     for (int i = 0; i < num_tb_variants(); i++) {
         const TbVariantInfo *v = tb_variant(i);
-        if (v->order != ord || v->kt != kt || v->radius != radius) continue;
+        if (v->order != ord || v->kt != kt || v->radius != radius || v->seg != 1) continue;  // (strip shapes only ever run a row's tail)
         if (v->shells && !shells_fit) continue;
         if (ctx->opt_tb_variant >= 0 ? idx == ctx->opt_tb_variant : !best) best = v;
         idx++;
@@ -723,7 +723,9 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
         if (rem <= 64 - 2 * ovq && v->rx == 2 && ctx->opt_tb_variant < 0)
             for (int i = 0; i < num_tb_variants(); i++) {
                 const TbVariantInfo *c = tb_variant(i);
-                if (c->order == v->order && c->kt == v->kt && c->radius == v->radius && c->nw == v->nw && c->ry == v->ry && c->rx == 1) narrow = c;
+                if (c->order != v->order || c->kt != v->kt || c->radius != v->radius || c->nw != v->nw || c->ry != v->ry || c->rx != 1) continue;
+                // the narrowest shape the tail fits: a strip (segments of 64/seg quads, each in another y tile) before the half-width tile
+                if (c->seg == 1 ? !narrow : (rem <= 64 / c->seg - 2 * ovq && !ctx->opt_no_strip && (!narrow || c->seg > narrow->seg))) narrow = c;
             }
         if (narrow) p.gx = gx_full - 1;
     }
@@ -761,13 +763,14 @@ static int launch_tb(fdtdx_ctx *ctx, const TbVariantInfo *v, float *out, const f
     if (narrow) {  // first the half-width tail (its grid is reported last otherwise), then the full-width tiles
         TbParams t = p;
         t.gx = 1, t.qbase = -ovq + (gx_full - 1) * p.qstep;
+        t.gy = (p.gy + narrow->seg - 1) / narrow->seg;
         if ((rc = launch_part(narrow, t))) return rc;
     }
     if ((rc = launch_part(v, p))) return rc;
     ctx->launches++;
     snprintf(ctx->last_fused, sizeof(ctx->last_fused), "fused%d kind=%u r=%d waves=%d rows/wave=%d quads/lane/row=%d tile_rows=%d(stored %d) threads=%d lds=%d grid=%dx%dx%d%s zchunk=%d",
              v->kt, prog->kind, v->radius, v->nw, v->ry, v->rx, v->nw * v->ry, owned, v->threads, v->lds_bytes, p.gx, p.gy, p.gz,
-             narrow ? "+half-width tail" : "", p.zchunk);
+             !narrow ? "" : narrow->seg > 1 ? "+strip tail" : "+half-width tail", p.zchunk);
     return FDTDX_OK;
 }
 
@@ -1478,6 +1481,8 @@ extern "C" int fdtdx_set_option(fdtdx_ctx *ctx, const char *key, int64_t value)
         ctx->opt_exchange_priority = value != 0;
     else if (!strcmp(key, "fuse_wide"))
         ctx->opt_fuse_wide = value != 0;
+    else if (!strcmp(key, "no_strip"))
+        ctx->opt_no_strip = value != 0;
     else if (!strcmp(key, "reserve_cus"))
         ctx->opt_reserve_cus = std::max<int64_t>(0, std::min<int64_t>(value, 255));
     else

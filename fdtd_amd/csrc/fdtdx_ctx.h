@@ -46,6 +46,7 @@ struct fdtdx_ctx {
     int64_t opt_fuse_wide = 0;         // 1: time loops may use the two-step kernels of radius 3 and 4 (slower than single steps: kept for measurement)
     int64_t opt_reserve_cus = 0;       // CUs a sweep launch leaves without a workgroup (room for the exchange's kernels)
     float *tb_scratch = nullptr;       // third cube of the fused time loop (owned)
+    int64_t opt_no_strip = 0;          // "no_strip": the tail of wide rows always goes to the half-width tile (measurement)
     float *stage = nullptr;            // staging buffer of the padded transfers (owned, allocated on first use)
     size_t stage_floats = 0;
     float *shell_strip[2] = {nullptr, nullptr};  // time loops: the shell components of the quads that straddle the x shell, per cube of the loop (owned)

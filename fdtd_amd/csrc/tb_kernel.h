@@ -126,10 +126,17 @@ __device__ __forceinline__ void level_step(float4 (&res)[RY][RX], const float4 (
     }
 }
 
-template <int KT, int NW, int RY, int RX, int ORDER>
+// SEG > 1: a "strip" shape for the few quads a row has left after its last full x tile.  Nothing in the march couples one lane with
+// another except the x-neighbour moves between adjacent lanes and the rows of other waves in the SAME lane, so a wave row of 64
+// lanes can just as well be SEG independent segments of 64/SEG quads: segment s of a workgroup works on y tile by*SEG + s of the
+// same narrow x range.  Only the per-lane constants know; each segment is an x tile with its one quad of overlap on either side
+// (what the lane moves carry across a segment's ends lands in those quads), 64/SEG - 2 quads stored.
+template <int KT, int NW, int RY, int RX, int ORDER, int SEG = 1>
 __global__ __launch_bounds__(NW * 64) void tb_r1_kernel(const TbParams p)
 {
     static_assert(KT == 2 || KT == 3, "two or three fused steps");
+    static_assert(SEG == 1 || (RX == 1 && 64 % SEG == 0 && 64 / SEG >= 4), "strips are cut out of single-quad wave rows");
+    constexpr int WQ = 64 * RX / SEG;   // quads of a tile row
     constexpr int ROWS = NW * RY;       // rows a tile loads
     constexpr int CYO = ROWS - 2 * KT;  // rows a tile stores
     static_assert(CYO > 0, "tile too small for its overlap");
@@ -157,7 +164,8 @@ __global__ __launch_bounds__(NW * 64) void tb_r1_kernel(const TbParams p)
     chunk_planes(p, bz, zs, ze, zrange_end);
     (void)zrange_end;
     if (zs >= ze) return;
-    const int yt0 = 1 - KT + by * CYO;  // first row the tile loads (may be negative)
+    const int seg = (SEG == 1) ? 0 : lane / WQ;    // per lane in a strip shape
+    const int yt0 = 1 - KT + (by * SEG + seg) * CYO;  // first row the tile loads (may be negative)
     const int yown0 = yt0 + KT, yown1 = yown0 + CYO;
 
     // ---- per-lane constants ---------------------------------------------------------------
@@ -173,10 +181,10 @@ __global__ __launch_bounds__(NW * 64) void tb_r1_kernel(const TbParams p)
         const bool yown = (y >= yown0) && (y < yown1);
 #pragma unroll
         for (int i = 0; i < RX; i++) {
-            const int lq = lane + 64 * i;
+            const int lq = (SEG == 1) ? lane + 64 * i : lane % WQ;
             const int qx = tq0 + lq;
             const int x0 = 4 * qx;
-            const bool xown = !xtiled || (lq >= 1 && lq < 64 * RX - 1);
+            const bool xown = !xtiled || (lq >= 1 && lq < WQ - 1);
             unsigned m = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++)
@@ -335,6 +343,7 @@ struct TbVariantInfo {
     int kt;     // fused steps per launch
     int radius; // 1 (tb_r1_kernel) or 2..4 (tb_rm_kernel)
     int nw, ry, rx, threads, lds_bytes;
+    int seg = 1;     // > 1: strip shape, a wave row is `seg` segments of 64/seg quads, each in another y tile
     int shells = 0;  // 1: honours TbParams::even and never writes a shell cell of `out` (in-place loops over two cubes)
     void (*launch)(const TbParams &, dim3 grid, hipStream_t);
 };
@@ -342,13 +351,13 @@ int num_tb_variants();
 const TbVariantInfo *tb_variant(int i);
 void register_tb_variant(const TbVariantInfo &v);
 
-template <int KT, int NW, int RY, int RX, int ORDER>
+template <int KT, int NW, int RY, int RX, int ORDER, int SEG>
 void tb_launch(const TbParams &p, dim3 grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((tb_r1_kernel<KT, NW, RY, RX, ORDER>), grid, dim3(NW * 64), 0, s, p);
+    hipLaunchKernelGGL((tb_r1_kernel<KT, NW, RY, RX, ORDER, SEG>), grid, dim3(NW * 64), 0, s, p);
 }
 
-template <int KT, int NW, int RY, int RX, int ORDER>
+template <int KT, int NW, int RY, int RX, int ORDER, int SEG = 1>
 struct TbRegistrar {
     TbRegistrar()
     {
@@ -359,12 +368,14 @@ struct TbRegistrar {
         v.nw = NW;
         v.ry = RY;
         v.rx = RX;
+        v.seg = SEG;
         v.threads = NW * 64;
         v.lds_bytes = (KT == 2 ? 2 : 1) * KT * NW * (RY == 1 ? 1 : 2) * RX * 64 * 16;
-        v.launch = &tb_launch<KT, NW, RY, RX, ORDER>;
+        v.launch = &tb_launch<KT, NW, RY, RX, ORDER, SEG>;
         register_tb_variant(v);
     }
 };
 #define FDTDX_TB_VARIANT(KT, NW, RY, RX, ORDER) static ::fdtdx::TbRegistrar<KT, NW, RY, RX, ORDER> tbreg_##KT##_##NW##_##RY##_##RX##_##ORDER;
+#define FDTDX_TB_STRIP_VARIANT(KT, NW, RY, ORDER, SEG) static ::fdtdx::TbRegistrar<KT, NW, RY, 1, ORDER, SEG> tbstrip_##KT##_##NW##_##RY##_##ORDER##_##SEG;
 
 }  // namespace fdtdx

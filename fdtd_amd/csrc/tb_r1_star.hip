@@ -14,3 +14,4 @@ FDTDX_TB_VARIANT(2, 6, 4, 2, ORD_STAR_CHAIN)
 FDTDX_TB_VARIANT(2, 6, 3, 2, ORD_STAR_CHAIN)
 FDTDX_TB_VARIANT(2, 16, 1, 2, ORD_STAR_CHAIN)
 FDTDX_TB_VARIANT(3, 16, 1, 1, ORD_STAR_CHAIN)  // half-width tile: the last x tile of rows wider than 128 quads
+FDTDX_TB_STRIP_VARIANT(3, 16, 1, ORD_STAR_CHAIN, 4)  // strip: rows with at most 14 quads left after their last full x tile

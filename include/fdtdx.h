@@ -392,7 +392,8 @@ int fdtdx_yee2d_steps(int device, float *ex, float *ey, float *hz, uint64_t nx, 
  * "exchange_priority" (1: the exchange stream of a communicator set up afterwards is created at the device's highest stream
  * priority; 0, default: an ordinary stream), "tb_variant" / "tb_zchunks" (shape and z-chunks of the fused kernel), "fuse_wide" (1: time loops and
  * fdtdx_propagate_fused_* may use the two-step kernels of star radius 3 and 4, which exist for measurement and run slower than
- * single steps; 0, default: those radii run one step per launch), "reserve_cus" (CUs a sweep launch leaves
+ * single steps; 0, default: those radii run one step per launch), "no_strip" (1: the few quads rows wider than one x tile have left
+ * after their last full tile go to the half-width tile instead of the strip shape; for measurement), "reserve_cus" (CUs a sweep launch leaves
  * without a workgroup when it sizes its grid: room for the exchange's kernels beside an interior sweep),
  * "boundary_stream" (0, default: fdtdx_step_begin / fdtdx_hop_begin queue the boundary-plane sweep in the caller's
  * stream, ahead of the interior sweep; 1: on a stream of the library's own, beside it -- measured slower where the

@@ -10,7 +10,7 @@ from fdtd_amd import Stencil, make_program, ORDER_CHAIN, ORDER_GOLDEN
 pytestmark = pytest.mark.gpu
 
 
-def run(cpu, kind, shape, steps, tb_variant=-1, tb_zchunks=0, temporal=1, M=1, golden=False, fuse_wide=0):
+def run(cpu, kind, shape, steps, tb_variant=-1, tb_zchunks=0, temporal=1, M=1, golden=False, fuse_wide=0, no_strip=0):
     Z, Y, X = shape
     if kind == "jacobi7":
         a = cpu.init_jacobi(Z, Y, X)
@@ -28,6 +28,7 @@ def run(cpu, kind, shape, steps, tb_variant=-1, tb_zchunks=0, temporal=1, M=1, g
         st.setOption("tb_variant", tb_variant)
         st.setOption("tb_zchunks", tb_zchunks)
         st.setOption("fuse_wide", fuse_wide)
+        st.setOption("no_strip", no_strip)
         st.sweep("p0", "p1", make_program(kind, radius=M, order=ORDER_GOLDEN if golden else ORDER_CHAIN), steps)
         st.sync()
         ga, gb = np.empty_like(a), np.empty_like(b)
@@ -85,6 +86,17 @@ def test_fused_wide_rows_are_cut_into_x_tiles(oracle_cpu, kt, kind, X):
     """Rows wider than a wave holds (X > 512) are fused too, as x tiles overlapping by one quad."""
     info = run(oracle_cpu, kind, (9, 30, X), 7, temporal=kt)
     assert f"fused{kt}" in info
+
+
+@pytest.mark.parametrize("shape", [(9, 130, 1024), (12, 47, 513), (9, 30, 1531), (14, 75, 1036)])
+@pytest.mark.parametrize("kind", ["star", "jacobi7"])
+def test_fused_strip_tail(oracle_cpu, kind, shape):
+    """The few quads a wide row has left after its last full x tile go to the strip shape (segments of 16 quads, each in another
+    y tile): several rows of strip workgroups, the last one ragged; the half-width tile in its place gives the same bits."""
+    info = run(oracle_cpu, kind, shape, 7, temporal=3, tb_zchunks=2)
+    assert "fused3" in info and "+strip tail" in info, info
+    info = run(oracle_cpu, kind, shape, 7, temporal=3, no_strip=1)
+    assert "fused3" in info and "+half-width tail" in info, info
 
 
 @pytest.mark.parametrize("steps", [4, 5, 6, 7, 8, 9, 11])
