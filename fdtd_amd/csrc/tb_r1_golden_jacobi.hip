@@ -5,3 +5,4 @@ using namespace fdtdx;
 FDTDX_TB_VARIANT(3, 16, 1, 2, ORD_JACOBI_GOLDEN)
 FDTDX_TB_VARIANT(2, 8, 3, 2, ORD_JACOBI_GOLDEN)
 FDTDX_TB_VARIANT(3, 16, 1, 1, ORD_JACOBI_GOLDEN)  // half-width tile: the last x tile of rows wider than 128 quads
+FDTDX_TB_STRIP_VARIANT(3, 16, 1, ORD_JACOBI_GOLDEN, 4)  // strip: rows with at most 14 quads left after their last full x tile

@@ -4,3 +4,4 @@
 using namespace fdtdx;
 FDTDX_TBM_VARIANT(2, 8, 2, 2, 1)
 FDTDX_TBM_VARIANT(2, 8, 2, 1, 1)  // half-width tile: the last x tile of rows wider than 128 quads
+FDTDX_TBM_STRIP_VARIANT(2, 8, 2, 1, 4)  // strip: rows with at most 14 quads left after their last full x tile

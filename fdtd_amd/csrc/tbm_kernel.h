@@ -95,10 +95,13 @@ __device__ __forceinline__ void star_rows(float4 (&res)[RY][RX], const float4 (&
     }
 }
 
-template <int M, int NW, int RY, int RX, int GOLDEN>
+// SEG > 1: the strip shape of tb_r1_kernel (tb_kernel.h): a wave row is SEG segments of 64/SEG quads, segment s in y tile by*SEG + s.
+template <int M, int NW, int RY, int RX, int GOLDEN, int SEG = 1>
 __global__ __launch_bounds__(NW * 64) void tb_rm_kernel(const TbParams p)
 {
     static_assert(M >= 2 && M <= 4, "x neighbours must lie in the adjacent quad");
+    static_assert(SEG == 1 || (RX == 1 && 64 % SEG == 0 && 64 / SEG >= 8), "strips are cut out of single-quad wave rows");
+    constexpr int WQ = 64 * RX / SEG;  // quads of a tile row
     constexpr int KT = 2;
     constexpr int QN = 2 * M + 1;
     constexpr int ROWS = NW * RY;
@@ -120,7 +123,8 @@ __global__ __launch_bounds__(NW * 64) void tb_rm_kernel(const TbParams p)
     chunk_planes(p, bz, zs, ze, zrange_end);
     (void)zrange_end;
     if (zs >= ze) return;
-    const int yt0 = M - KT * M + by * CYO;  // first row the tile loads (may be negative)
+    const int seg = (SEG == 1) ? 0 : lane / WQ;            // per lane in a strip shape
+    const int yt0 = M - KT * M + (by * SEG + seg) * CYO;  // first row the tile loads (may be negative)
     const int yown0 = yt0 + KT * M, yown1 = yown0 + CYO;
 
     unsigned goff[RY][RX], moff[RY][RX], soff[RY][RX], imask[RY][RX];
@@ -132,13 +136,13 @@ __global__ __launch_bounds__(NW * 64) void tb_rm_kernel(const TbParams p)
         const bool yown = (y >= yown0) && (y < yown1);
 #pragma unroll
         for (int i = 0; i < RX; i++) {
-            const int lq = lane + 64 * i;
+            const int lq = (SEG == 1) ? lane + 64 * i : lane % WQ;
             const int qx = tq0 + lq;
             const int x0 = 4 * qx;
             // x tiles overlap by the quads two levels reach into (one for radius 2, two for radius 3 and 4): a tile's
             // outermost OVQ quads on either side are a neighbouring tile's to store
             constexpr int OVQ = (KT * M + 3) / 4;
-            const bool xown = !xtiled || (lq >= OVQ && lq < 64 * RX - OVQ);
+            const bool xown = !xtiled || (lq >= OVQ && lq < WQ - OVQ);
             unsigned m = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++)
@@ -260,13 +264,13 @@ __global__ __launch_bounds__(NW * 64) void tb_rm_kernel(const TbParams p)
     }
 }
 
-template <int M, int NW, int RY, int RX, int GOLDEN>
+template <int M, int NW, int RY, int RX, int GOLDEN, int SEG>
 void tbm_launch(const TbParams &p, dim3 grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((tb_rm_kernel<M, NW, RY, RX, GOLDEN>), grid, dim3(NW * 64), 0, s, p);
+    hipLaunchKernelGGL((tb_rm_kernel<M, NW, RY, RX, GOLDEN, SEG>), grid, dim3(NW * 64), 0, s, p);
 }
 
-template <int M, int NW, int RY, int RX, int GOLDEN>
+template <int M, int NW, int RY, int RX, int GOLDEN, int SEG = 1>
 struct TbmRegistrar {
     TbmRegistrar()
     {
@@ -277,12 +281,14 @@ struct TbmRegistrar {
         v.nw = NW;
         v.ry = RY;
         v.rx = RX;
+        v.seg = SEG;
         v.threads = NW * 64;
         v.lds_bytes = 2 * 2 * NW * RY * RX * 64 * 16;
-        v.launch = &tbm_launch<M, NW, RY, RX, GOLDEN>;
+        v.launch = &tbm_launch<M, NW, RY, RX, GOLDEN, SEG>;
         register_tb_variant(v);
     }
 };
 #define FDTDX_TBM_VARIANT(M, NW, RY, RX, GOLDEN) static ::fdtdx::TbmRegistrar<M, NW, RY, RX, GOLDEN> tbmreg_##M##_##NW##_##RY##_##RX##_##GOLDEN;
+#define FDTDX_TBM_STRIP_VARIANT(M, NW, RY, GOLDEN, SEG) static ::fdtdx::TbmRegistrar<M, NW, RY, 1, GOLDEN, SEG> tbmstrip_##M##_##NW##_##RY##_##GOLDEN##_##SEG;
 
 }  // namespace fdtdx

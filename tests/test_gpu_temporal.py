@@ -99,6 +99,19 @@ def test_fused_strip_tail(oracle_cpu, kind, shape):
     assert "fused3" in info and "+half-width tail" in info, info
 
 
+@pytest.mark.parametrize("golden", [False, True])
+@pytest.mark.parametrize("shape", [(13, 130, 1024), (14, 47, 513), (13, 75, 1036)])
+def test_fused_strip_tail_radius2_and_host_order(oracle_cpu, shape, golden):
+    info = run(oracle_cpu, "star", shape, 7, M=2, tb_zchunks=2, golden=golden)
+    assert "fused2" in info and "+strip tail" in info, info
+    info = run(oracle_cpu, "star", shape, 7, M=2, no_strip=1, golden=golden)
+    assert "fused2" in info and "+half-width tail" in info, info
+    if golden:
+        for kind in ("star", "jacobi7"):
+            info = run(oracle_cpu, kind, shape, 7, temporal=3, golden=True)
+            assert "fused3" in info and "+strip tail" in info, info
+
+
 @pytest.mark.parametrize("steps", [4, 5, 6, 7, 8, 9, 11])
 def test_fused_radius2_step_counts(oracle_cpu, steps):
     """fdtd2's update fused two steps per launch (tbm_kernel.h): several y tiles and z chunks, ragged x."""
