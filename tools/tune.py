@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--temporal", type=int, default=0, help="1: let sweep() fuse time steps")
     ap.add_argument("--tb-variant", type=int, default=-1, help="shape index of the fused kernel (-1: default)")
+    ap.add_argument("--tb-zchunks", type=int, default=0, help="z chunks of the fused kernel (0: the library's choice)")
     ap.add_argument("--variants", default="", help="comma list of variant indices (default: all)")
     ap.add_argument("--bounded", type=int, default=1,
                     help="1 (default): star coefficients are divided by their sum (0.01 + 0.27 M), so the fields stay finite however many steps "
@@ -43,6 +44,7 @@ def main():
                 st.initMt("p0", "p1")
                 st.setOption("temporal", a.temporal)
                 st.setOption("tb_variant", a.tb_variant)
+                st.setOption("tb_zchunks", a.tb_zchunks)
                 prog = make_program(kind, radius=M)
                 if a.bounded and kind == "star":
                     for i in range(13):
