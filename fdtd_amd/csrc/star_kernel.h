@@ -102,9 +102,35 @@ constexpr int star_nhk(int M, int TQ, int LY, int RY)
 #ifndef FDTDX_EO_SAME_STEP
 #define FDTDX_EO_SAME_STEP -1
 #endif
+// The shapes that run adjacent row pairs on 512 lanes together with the late publish (both described below): radius 8 on tiles of
+// 16 x 64 and 32 x 32 quads x rows, radius 7 on 32 x 32.  With 256 registers per lane the two queues fit without the squeeze of the
+// 1024-lane shapes, the pair reads 2M + 8 quads from LDS per plane instead of 2 (2M + 4), and the publish hides behind the
+// arithmetic.  What that is worth depends on the values in the cubes (the sweeps run at the power limit): at 512^3 on fields kept
+// near 0.5 by normalised coefficients radius 8 takes 224-229 us per sweep on 16 x 64 tiles and 231-234 on 32 x 32 against 237-244
+// for 32 x 32 tiles on 1024 lanes (and 297 for the 16 x 64 tile with rows LY apart and the early publish); on the drivers' own
+// fields, which grow by a factor of two per step, 232.7 (32 x 32) and 233-236 (16 x 64) against 235.7.  Radius 7: 213 against 217
+// on the normalised fields, 220.5 against 217.3 on the drivers'.  Radius 5 and 6 gain nothing either way.
+constexpr bool star_pairs_late(int M, int TQ, int LY, int RY, int ORDER)
+{
+    return ORDER == ORD_STAR_CHAIN && RY == 2 && ((M == 8 && ((TQ == 16 && LY == 32) || (TQ == 32 && LY == 16))) || (M == 7 && TQ == 32 && LY == 16));
+}
+// Adjacent rows: a lane with two rows owns rows 2*ty and 2*ty+1 instead of ty and ty+LY.  The y neighbours of the two rows then
+// overlap (rows -M .. M+1 around the first: 2M reads from LDS for the pair instead of 4M, the two own quads come from registers);
+// the update walks the radius once for both rows and hands each neighbour quad from the row that reads it first to the other.
+// FDTDX_ADJ_ROWS = 0 or 1 forces either for every two-row kernel of a translation unit (experiments).
+#ifndef FDTDX_ADJ_ROWS
+#define FDTDX_ADJ_ROWS -1
+#endif
+constexpr bool star_adjacent(int M, int TQ, int LY, int RY, int ORDER)
+{
+    if (RY != 2 || !(ORDER == ORD_STAR_CHAIN || ORDER == ORD_STAR_GOLDEN)) return false;
+    if (FDTDX_ADJ_ROWS >= 0) return FDTDX_ADJ_ROWS != 0;
+    return star_pairs_late(M, TQ, LY, RY, ORDER);
+}
 constexpr bool star_late(int M, int TQ, int LY, int RY, int ORDER)
 {
     if (FDTDX_LATE_PUBLISH >= 0) return FDTDX_LATE_PUBLISH != 0;
+    if (star_pairs_late(M, TQ, LY, RY, ORDER)) return true;
     return ORDER == ORD_STAR_CHAIN && (M == 7 || M == 8) && TQ == 32 && LY == 32 && RY == 1;
 }
 constexpr bool star_eo_same_step(int M, int TQ, int LY, int RY, int ORDER)
@@ -258,6 +284,54 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
     if constexpr (!LATE && !(FDTDX_ABLATE & 32)) __syncthreads();
 
     const float c0 = c[0], cxp = c[1], cxm = c[2], cyp = c[3], cym = c[4], czp = c[5], czm = c[6];
+    constexpr bool ADJ = star_adjacent(M, TQ, LY, RY, ORDER);
+    float adj_acc[RY][4];
+    if constexpr (ADJ) {
+        // rows y and y+1 of one lane together: R(k) = the quad k rows below the first row's.  Row 0 reads R(-r) and R(r), row 1
+        // R(1-r) and R(r+1): every quad but R(-M) and R(M+1) serves both rows, a radius step apart, and R(0), R(1) are the own quads
+        constexpr int XB = 4 * HQ;
+        float xw[2][4 * (2 * HQ + 1)];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const float4 *row = buf + L.lown[j];
+#pragma unroll
+            for (int s = -HQ; s <= HQ; s++) {
+                float4 v;
+                if (s == 0) {
+                    v = q[j][QS(M)];
+                } else {
+                    f32x4 w = *reinterpret_cast<const f32x4 *>(&row[s]);
+                    if (M % 4 != 0 && (s == -HQ || s == HQ)) asm("" : "+v"(w));  // whole-quad read (see the one-row path below)
+                    v = make_float4(w[0], w[1], w[2], w[3]);
+                }
+                xw[j][4 * (s + HQ) + 0] = v.x, xw[j][4 * (s + HQ) + 1] = v.y, xw[j][4 * (s + HQ) + 2] = v.z, xw[j][4 * (s + HQ) + 3] = v.w;
+            }
+        }
+#define XW(j, i) f32x2{xw[j][(i)], xw[j][(i) + 1]}
+        f32x2 a01[2] = {c0 * XW(0, XB), c0 * XW(1, XB)}, a23[2] = {c0 * XW(0, XB + 2), c0 * XW(1, XB + 2)};
+        const float4 *r0 = buf + L.lown[0];
+        float4 up_prev = q[0][QS(M)], dn_prev = q[1][QS(M)];
+#pragma unroll
+        for (int r = 1; r <= M; r++) {
+            const float4 up0 = r0[-r * LPQ], dn1 = r0[(r + 1) * LPQ];
+            const float4 ypj[2] = {dn_prev, dn1}, ymj[2] = {up0, up_prev};
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const float4 yp = ypj[j], ym = ymj[j];
+                const float4 zp = q[j][QS(M + r)], zm = q[j][QS(M - r)];
+                a01[j] = pair_or_chain2<ORDER>(a01[j], cxp, XW(j, XB + r), cxm, XW(j, XB - r));
+                a01[j] = pair_or_chain2<ORDER>(a01[j], cyp, f32x2{yp.x, yp.y}, cym, f32x2{ym.x, ym.y});
+                a01[j] = pair_or_chain2<ORDER>(a01[j], czp, f32x2{zp.x, zp.y}, czm, f32x2{zm.x, zm.y});
+                a23[j] = pair_or_chain2<ORDER>(a23[j], cxp, XW(j, XB + 2 + r), cxm, XW(j, XB + 2 - r));
+                a23[j] = pair_or_chain2<ORDER>(a23[j], cyp, f32x2{yp.z, yp.w}, cym, f32x2{ym.z, ym.w});
+                a23[j] = pair_or_chain2<ORDER>(a23[j], czp, f32x2{zp.z, zp.w}, czm, f32x2{zm.z, zm.w});
+            }
+            up_prev = up0, dn_prev = dn1;
+        }
+#undef XW
+#pragma unroll
+        for (int j = 0; j < 2; j++) adj_acc[j][0] = a01[j].x, adj_acc[j][1] = a01[j].y, adj_acc[j][2] = a23[j].x, adj_acc[j][3] = a23[j].y;
+    }
 #pragma unroll
     for (int j = 0; j < RY; j++) {
         const float4 *row = buf + L.lown[j];
@@ -338,6 +412,8 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
                 }
                 buf_st4(make_rsrc(cs.ps, plane_bytes), L.soff[j], sv[0], sv[1], sv[2], sv[3]);
             }
+        } else if constexpr (ADJ) {
+            acc[0] = adj_acc[j][0], acc[1] = adj_acc[j][1], acc[2] = adj_acc[j][2], acc[3] = adj_acc[j][3];
         } else if constexpr ((FDTDX_ABLATE & 1) != 0) {
             acc[0] = xs[XB] + hv[0].x, acc[1] = xs[XB + 1], acc[2] = xs[XB + 2], acc[3] = xs[XB + 3];  // (the halo loads stay alive)
         } else if constexpr (ORDER == ORD_STAR_CHAIN || ORDER == ORD_STAR_GOLDEN) {
@@ -443,7 +519,8 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
     const bool many = L.m0 || L.m1 || L.m2 || L.m3;
 #pragma unroll
     for (int j = 0; j < RY; j++) {
-        const int y = y0 + ty + j * LY;
+        const int lrow_own = star_adjacent(M, TQ, LY, RY, ORDER) ? RY * ty + j : ty + j * LY;  // row of the tile
+        const int y = y0 + lrow_own;
         const unsigned off = (unsigned)(y * p.px + 4 * qx) * 4u;
         const bool rok = qok && (y < p.ny);
         const bool cok = qok && (y < p.ny - p.h) && many;
@@ -453,7 +530,7 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
         L.eoff[j] = (cok && (!mall || is_composite(ORDER))) ? off : OOB;
         if (!is_composite(ORDER) && p.shell)  // strip entry (row, side): the left such quad of a row is the one whose first cell is shell
             L.eoff[j] = (cok && !mall) ? (unsigned)(2 * y + (L.m0 ? 1 : 0)) * 16u : OOB;
-        L.lown[j] = (M + ty + j * LY) * LPQ + HQ + tx;
+        L.lown[j] = (M + lrow_own) * LPQ + HQ + tx;
         L.yrow[j] = y;
     }
     // ---- halo quads assigned to this thread --------------------------------------------------
