@@ -448,8 +448,14 @@ static int check_program(const fdtdx_ctx *ctx, const fdtdx_program *prog, int *r
 // Default tile shape per radius (quads x thread-rows x rows-per-thread).  Tile shapes measured fastest at 512^3 (tools/tune.py).  Radius <= 4 runs full-row tiles (no x
 // halo at X <= 512) when the grid is wide enough to fill them; larger radii need the registers
 // for the z queue and use 32-quad tiles.
-static void default_shape(int kind, int r, int nq, int *tq, int *ly, int *ry)
+static void default_shape(int kind, int r, int nq, int *tq, int *ly, int *ry, unsigned order = FDTDX_ORDER_CHAIN)
 {
+    if (kind == FDTDX_STAR && order == FDTDX_ORDER_GOLDEN && r >= 5) {
+        // separate multiplies and adds: twice the arithmetic, and the 1024-lane shapes spill; 32-quad tiles on 512 lanes, at radius 5
+        // with two adjacent rows per lane
+        *tq = 32, *ly = 16, *ry = r == 5 ? 2 : 1;
+        return;
+    }
     if (kind == FDTDX_SPC13) {
         *tq = 64, *ly = 8, *ry = 2;
         return;
@@ -537,7 +543,7 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
     int tq, ly, ry, threads, lds, pf = 1;
     void (*launch)(const SweepParams &, dim3, hipStream_t) = nullptr;
     int dtq, dly, dry;
-    default_shape(prog->kind, r, (int)((ctx->cfg.X + 3) / 4), &dtq, &dly, &dry);
+    default_shape(prog->kind, r, (int)((ctx->cfg.X + 3) / 4), &dtq, &dly, &dry, comp ? FDTDX_ORDER_CHAIN : prog->order);
     if (comp && ctx->cfg.X >= 128) dtq = 32, dly = 16, dry = 2;  // three or four input streams: measured 5-8 % ahead of full-row tiles
     if (prog->kind == FDTDX_SPC13) {
         const SpcVariantInfo *best = nullptr;

@@ -125,12 +125,16 @@ constexpr bool star_adjacent(int M, int TQ, int LY, int RY, int ORDER)
 {
     if (RY != 2 || !(ORDER == ORD_STAR_CHAIN || ORDER == ORD_STAR_GOLDEN)) return false;
     if (FDTDX_ADJ_ROWS >= 0) return FDTDX_ADJ_ROWS != 0;
+    // the host loops' order at radius 5: 32 x 32 tiles on 512 lanes run 527 Gcell/s with rows LY apart, 557-567 with adjacent rows
+    // (one row per lane on 32 x 16 tiles: 487-493; from radius 6 up two rows per lane spill in this order)
+    if (ORDER == ORD_STAR_GOLDEN && M == 5 && TQ == 32 && LY == 16) return true;
     return star_pairs_late(M, TQ, LY, RY, ORDER);
 }
 constexpr bool star_late(int M, int TQ, int LY, int RY, int ORDER)
 {
     if (FDTDX_LATE_PUBLISH >= 0) return FDTDX_LATE_PUBLISH != 0;
     if (star_pairs_late(M, TQ, LY, RY, ORDER)) return true;
+    if (ORDER == ORD_STAR_GOLDEN && M == 8 && TQ == 32 && LY == 16 && RY == 1) return true;  // 385-388 -> 408-417 Gcell/s at 512^3 (radius 5-7: no gain)
     return ORDER == ORD_STAR_CHAIN && (M == 7 || M == 8) && TQ == 32 && LY == 32 && RY == 1;
 }
 constexpr bool star_eo_same_step(int M, int TQ, int LY, int RY, int ORDER)
