@@ -476,7 +476,7 @@ static void default_shape(int kind, int r, int nq, int *tq, int *ly, int *ry, un
         return;
     }
     switch (r) {
-    case 5: *tq = 32, *ly = 24, *ry = 1; break;  // 768 lanes, 84 tiles x 3 z chunks at 512^3: 4.5 % ahead of 64 x 16 on 1024 lanes (radius 6: level; 7, 8: behind)
+    case 5: *tq = 64, *ly = 16, *ry = 1; break;  // (launch_sweep prefers a 768-lane shape where its tiles fill the CUs)
     case 6: *tq = 32, *ly = 16, *ry = 2; break;  // 32 x 32 cells on 512 lanes: 2.5 % ahead of 64 x 16 in a time loop
     case 7: *tq = 32, *ly = 32, *ry = 1; break;  // level with 32 x 16 in a lone sweep, 6 % ahead of it in a time loop (shell strips)
     // radius 8: the same 32 x 32 tile on 512 lanes, every lane two adjacent rows, late publish (star_pairs_late in star_kernel.h):
@@ -545,18 +545,21 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
     int dtq, dly, dry;
     default_shape(prog->kind, r, (int)((ctx->cfg.X + 3) / 4), &dtq, &dly, &dry, comp ? FDTDX_ORDER_CHAIN : prog->order);
     if (comp && ctx->cfg.X >= 128) dtq = 32, dly = 16, dry = 2;  // three or four input streams: measured 5-8 % ahead of full-row tiles
-    if (!comp && prog->kind == FDTDX_STAR && prog->order == FDTDX_ORDER_CHAIN && r == 5) {
-        // the 768-lane shape pays where its tiles fill the CUs (84 tiles x 3 z chunks on planes of 512 x 512 cells); where they do not
-        // (344 tiles on planes of 1024 x 1024: a second, mostly empty round; 461 against 620 Gcell/s) the 1024-lane shape stays
+    if (!comp && prog->kind == FDTDX_STAR && prog->order == FDTDX_ORDER_CHAIN && (r == 4 || r == 5)) {
+        // 768-lane shapes (12 waves, 84 tiles x 3 z chunks on planes of 512 x 512 cells: a z chunk re-reads 2r planes, and three chunks
+        // re-read fewer than four): radius 5 on 32 x 24 tiles 596 -> 622 Gcell/s, radius 4 on 64 x 12 tiles 637 -> 643 (radius 6: level;
+        // 3, 7, 8: behind).  Only where the tiles fill the CUs: 344 tiles on planes of 1024 x 1024 need a second, mostly empty round
+        // (radius 5: 461 against 620 Gcell/s), there the 1024-lane shape stays.
+        const int ptq = r == 5 ? 32 : 64, ply = r == 5 ? 24 : 12;
         const long long cus = std::max<long long>(1, ctx->num_cus - ctx->opt_reserve_cus);
         const long long nz0 = std::max<long long>((long long)(z_hi - z_lo), z2_lo < z2_hi ? (long long)(z2_hi - z2_lo) : 0);
-        const long long tiles = (long long)(((ctx->cfg.X + 3) / 4 + dtq - 1) / dtq) * (((long long)ctx->cfg.Y - 2 * r + dly * dry - 1) / (dly * dry)) * (z2_lo < z2_hi ? 2 : 1);
+        const long long tiles = (long long)(((ctx->cfg.X + 3) / 4 + ptq - 1) / ptq) * (((long long)ctx->cfg.Y - 2 * r + ply - 1) / ply) * (z2_lo < z2_hi ? 2 : 1);
         double fill;
         if (tiles >= cus)
             fill = (double)tiles / (double)(((tiles + cus - 1) / cus) * cus);
         else
             fill = (double)(tiles * std::max<long long>(1, std::min(cus / tiles, std::max<long long>(1, nz0 / (12LL * r))))) / (double)cus;
-        if (fill < 0.95) dtq = 64, dly = 16, dry = 1;
+        if (fill >= 0.95) dtq = ptq, dly = ply, dry = 1;
     }
     if (prog->kind == FDTDX_SPC13) {
         const SpcVariantInfo *best = nullptr;
