@@ -545,12 +545,13 @@ static int launch_sweep(fdtdx_ctx *ctx, float *out, const float *in, const fdtdx
     int dtq, dly, dry;
     default_shape(prog->kind, r, (int)((ctx->cfg.X + 3) / 4), &dtq, &dly, &dry, comp ? FDTDX_ORDER_CHAIN : prog->order);
     if (comp && ctx->cfg.X >= 128) dtq = 32, dly = 16, dry = 2;  // three or four input streams: measured 5-8 % ahead of full-row tiles
-    if (!comp && prog->kind == FDTDX_STAR && prog->order == FDTDX_ORDER_CHAIN && (r == 4 || r == 5)) {
+    if (!comp && prog->kind == FDTDX_STAR && (prog->order == FDTDX_ORDER_CHAIN ? (r == 4 || r == 5) : (r == 6 || r == 7))) {
         // 768-lane shapes (12 waves, 84 tiles x 3 z chunks on planes of 512 x 512 cells: a z chunk re-reads 2r planes, and three chunks
         // re-read fewer than four): radius 5 on 32 x 24 tiles 596 -> 622 Gcell/s, radius 4 on 64 x 12 tiles 637 -> 643 (radius 6: level;
         // 3, 7, 8: behind).  Only where the tiles fill the CUs: 344 tiles on planes of 1024 x 1024 need a second, mostly empty round
-        // (radius 5: 461 against 620 Gcell/s), there the 1024-lane shape stays.
-        const int ptq = r == 5 ? 32 : 64, ply = r == 5 ? 24 : 12;
+        // (radius 5: 461 against 620 Gcell/s), there the 1024-lane shape stays.  The host order takes 32 x 24 tiles at radius 6 and 7 (twelve
+        // waves per CU instead of the eight of its 512-lane shape: 475 -> 505 and 427 -> 445 Gcell/s; at radius 8 they spill).
+        const int ptq = r == 4 ? 64 : 32, ply = r == 4 ? 12 : 24;
         const long long cus = std::max<long long>(1, ctx->num_cus - ctx->opt_reserve_cus);
         const long long nz0 = std::max<long long>((long long)(z_hi - z_lo), z2_lo < z2_hi ? (long long)(z2_hi - z2_lo) : 0);
         const long long tiles = (long long)(((ctx->cfg.X + 3) / 4 + ptq - 1) / ptq) * (((long long)ctx->cfg.Y - 2 * r + ply - 1) / ply) * (z2_lo < z2_hi ? 2 : 1);
