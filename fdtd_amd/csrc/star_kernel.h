@@ -79,6 +79,7 @@ constexpr int star_nhk(int M, int TQ, int LY, int RY)
 //   1: no neighbour reads and no arithmetic (the result is the own quad)      2: the halo quads skip the LDS ring (dropped)
 //   4: no halo loads        8: no re-read of the output's shell components    16: no store        32: no LDS publish, no barrier
 //   64: the y neighbours are not read from LDS (the own quad stands in: same arithmetic)   128: nor the x neighbours
+//   256: the halo quads left and right of the tile are not loaded (the loads are issued with an out-of-range offset)   512: nor those above and below
 #ifndef FDTDX_ABLATE
 #define FDTDX_ABLATE 0
 #endif
@@ -301,7 +302,7 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
 #pragma unroll
             for (int s = -HQ; s <= HQ; s++) {
                 float4 v;
-                if (s == 0) {
+                if (s == 0 || (FDTDX_ABLATE & 128)) {
                     v = q[j][QS(M)];
                 } else {
                     f32x4 w = *reinterpret_cast<const f32x4 *>(&row[s]);
@@ -317,7 +318,7 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
         float4 up_prev = q[0][QS(M)], dn_prev = q[1][QS(M)];
 #pragma unroll
         for (int r = 1; r <= M; r++) {
-            const float4 up0 = r0[-r * LPQ], dn1 = r0[(r + 1) * LPQ];
+            const float4 up0 = (FDTDX_ABLATE & 64) ? q[0][QS(M)] : r0[-r * LPQ], dn1 = (FDTDX_ABLATE & 64) ? q[1][QS(M)] : r0[(r + 1) * LPQ];
             const float4 ypj[2] = {dn_prev, dn1}, ymj[2] = {up0, up_prev};
 #pragma unroll
             for (int j = 0; j < 2; j++) {
@@ -336,6 +337,7 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
 #pragma unroll
         for (int j = 0; j < 2; j++) adj_acc[j][0] = a01[j].x, adj_acc[j][1] = a01[j].y, adj_acc[j][2] = a23[j].x, adj_acc[j][3] = a23[j].y;
     }
+    constexpr bool ADJ_MATH = ADJ && !(FDTDX_ABLATE & 1);
 #pragma unroll
     for (int j = 0; j < RY; j++) {
         const float4 *row = buf + L.lown[j];
@@ -416,7 +418,7 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
                 }
                 buf_st4(make_rsrc(cs.ps, plane_bytes), L.soff[j], sv[0], sv[1], sv[2], sv[3]);
             }
-        } else if constexpr (ADJ) {
+        } else if constexpr (ADJ_MATH) {
             acc[0] = adj_acc[j][0], acc[1] = adj_acc[j][1], acc[2] = adj_acc[j][2], acc[3] = adj_acc[j][3];
         } else if constexpr ((FDTDX_ABLATE & 1) != 0) {
             acc[0] = xs[XB] + hv[0].x, acc[1] = xs[XB + 1], acc[2] = xs[XB + 2], acc[3] = xs[XB + 3];  // (the halo loads stay alive)
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(TQ *LY) void star_sweep_kernel(const SweepParams p)
         const int gy = y0 - M + lrow;
         const int gq = q0 - HQ + lcol;
         const bool hin = (k < NHK - 1) || (hidx < NHQ);
-        const bool hok = hin && (gy < p.ny) && (gq >= 0) && (gq < p.pxq);
+        const bool hok = hin && (gy < p.ny) && (gq >= 0) && (gq < p.pxq) && !((FDTDX_ABLATE & 256) && hidx >= NHY) && !((FDTDX_ABLATE & 512) && hidx < NHY);
         L.hgoff[k] = hok ? (unsigned)(gy * p.px + 4 * gq) * 4u : OOB;
         L.hloff[k] = hin ? lrow * LPQ + lcol : -1;
     }
