@@ -79,6 +79,7 @@ constexpr int star_nhk(int M, int TQ, int LY, int RY)
 //   1: no neighbour reads and no arithmetic (the result is the own quad)      2: the halo quads skip the LDS ring (dropped)
 //   4: no halo loads        8: no re-read of the output's shell components    16: no store        32: no LDS publish, no barrier
 //   64: the y neighbours are not read from LDS (the own quad stands in: same arithmetic)   128: nor the x neighbours
+//   1024: the last (partial) round of halo quads is skipped altogether: no load, no ring entry, no publish
 //   256: the halo quads left and right of the tile are not loaded (the loads are issued with an out-of-range offset)   512: nor those above and below
 #ifndef FDTDX_ABLATE
 #define FDTDX_ABLATE 0
@@ -220,6 +221,7 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
                 const int hidx = (int)threadIdx.x + k * NT;
                 // a wave whose lanes all lie past the last halo quad has none in this round and skips the ring (radius 8, 32 x 32
                 // quads: 6 of 16 waves, 2.5 % of the sweep's time; radius 7: 1 %)
+                if ((FDTDX_ABLATE & 1024) && NHK > 1 && k == NHK - 1) continue;
                 if (k == NHK - 1 && __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) * 64 + k * NT >= NHQ) continue;
                 float4 *rs = ring + ((k < NHK - 1 || hidx < NHQ) ? rslot * NHQ + hidx : RP * NHQ + hidx - NHQ);
                 const float4 h = *rs;
@@ -255,7 +257,7 @@ __device__ __forceinline__ void plane_step(float4 (&q)[RY][2 * M + 1 + PF], floa
             // ring: the halo of the plane the own quads are fetched of (only planes that become a centre plane of this chunk need
             // one); no ring: the halo of the next plane to be published
 #pragma unroll
-            for (int k = 0; k < NHK; k++) hv[k] = RP > 0 ? buf_ld4(rn, more_h ? L.hgoff[k] : OOB) : buf_ld4(rc, L.hgoff[k]);
+            for (int k = 0; k < ((FDTDX_ABLATE & 1024) && NHK > 1 ? NHK - 1 : NHK); k++) hv[k] = RP > 0 ? buf_ld4(rn, more_h ? L.hgoff[k] : OOB) : buf_ld4(rc, L.hgoff[k]);
         }
     };
     float4 eo_cur[RY], vq_cur[RY], sq_cur[RY];
