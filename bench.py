@@ -185,6 +185,8 @@ def main():
                     help="tuning: index of the single-step kernel's tile shape among the compiled ones (tools/tune.py lists them); -1 = the library's choice")
     ap.add_argument("--fuse-wide", action="store_true",
                     help="one rank: run radius 3 and 4 through their two-step kernels (slower than single steps; kept for measurement)")
+    ap.add_argument("--no-strip", action="store_true",
+                    help="tuning: rows wider than the fused kernels' tiles run their last few quads through the half-width tile instead of the strip shape")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-standing-start", dest="standing_start", action="store_false",
                     help="skip the extra 1000-step run from a standing start (one rank, sweep variants)")
@@ -431,6 +433,8 @@ def main():
             be.st.initMt("p0", "p1")
         prog = make_program(kind, radius=radius, order=ORDER_GOLDEN if a.order == "golden" else ORDER_CHAIN)
         be.st.setOption("temporal", a.temporal)
+        if a.no_strip:
+            be.st.setOption("no_strip", 1)
         if a.shape >= 0:
             be.st.setOption("variant", a.shape)
         # the two-step loops that hop through a third cube (radius 2; radius 1 under --temporal 2) get it from here, by name:

@@ -109,13 +109,19 @@ __device__ __forceinline__ float4 select4(unsigned m, const float4 &a, const flo
     return make_float4((m & 1u) ? a.x : b.x, (m & 2u) ? a.y : b.y, (m & 4u) ? a.z : b.z, (m & 8u) ? a.w : b.w);
 }
 
-template <int NW, int RY, int RX, int GOLDEN>
+// SEG > 1: the strip shape of tb_kernel.h for the few quads a row has left after its last full x tile: a wave row is SEG
+// independent segments of 64/SEG quads, segment s working on y tile by*SEG + s.  What differs from one lane to the next
+// then includes the row: "this row is shell throughout" is a per-lane fact (a wave's segments lie in different y tiles), so
+// the choice between two buffer descriptors that the whole-width shapes make per wave becomes two loads and a select.
+template <int NW, int RY, int RX, int GOLDEN, int SEG = 1>
 __global__ __launch_bounds__(NW * 64) void tb_spc_kernel(const TbParams p)
 {
     constexpr int KT = 2;
     constexpr int ROWS = NW * RY;
     constexpr int CYO = ROWS - 2 * KT;  // rows a tile stores
     static_assert(CYO > 0, "tile too small for its overlap");
+    static_assert(SEG == 1 || (RX == 1 && 64 % SEG == 0 && 64 / SEG >= 4), "strips are cut out of single-quad wave rows");
+    constexpr int WQ = 64 * RX / SEG;  // quads of a tile row
     // rows the waves show each other, per level: [first row @newest plane | first row @centre plane | last row @centre plane |
     // last row @oldest plane][quad column][lane].  One buffer: written at the top of an iteration, read during it, with a
     // barrier on either side.
@@ -135,7 +141,8 @@ __global__ __launch_bounds__(NW * 64) void tb_spc_kernel(const TbParams p)
     chunk_planes(p, bz, zs, ze, zrange_end);
     (void)zrange_end;
     if (zs >= ze) return;
-    const int yt0 = 1 - KT + by * CYO;  // first row the tile loads (may be negative)
+    const int seg = (SEG == 1) ? 0 : lane / WQ;          // per lane in a strip shape
+    const int yt0 = 1 - KT + (by * SEG + seg) * CYO;  // first row the tile loads (may be negative)
     const int yown0 = yt0 + KT, yown1 = yown0 + CYO;
 
     // per quad: byte offset inside a plane (rows/quads outside the plane: out of range) and flags:
@@ -155,10 +162,10 @@ __global__ __launch_bounds__(NW * 64) void tb_spc_kernel(const TbParams p)
         shq[j] = OOB;
 #pragma unroll
         for (int i = 0; i < RX; i++) {
-            const int lq = lane + 64 * i;
+            const int lq = (SEG == 1) ? lane + 64 * i : lane % WQ;
             const int qx = tq0 + lq;
             const int x0 = 4 * qx;
-            const bool xown = !xtiled || (lq >= 1 && lq < 64 * RX - 1);
+            const bool xown = !xtiled || (lq >= 1 && lq < WQ - 1);
             unsigned m = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++)
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(NW * 64) void tb_spc_kernel(const TbParams p)
             if (qdom && yin && x0 < p.nx && m != 0xFu) shq[j] = goff[j][i];
         }
     }
-    yfull = __builtin_amdgcn_readfirstlane(yfull);
+    if constexpr (SEG == 1) yfull = __builtin_amdgcn_readfirstlane(yfull);  // (per lane in a strip)
     float c[13];
 #pragma unroll
     for (int k = 0; k < 13; k++) c[k] = p.c[k];
@@ -185,7 +192,20 @@ __global__ __launch_bounds__(NW * 64) void tb_spc_kernel(const TbParams p)
         const bool zsh = zshell(z);
 #pragma unroll
         for (int j = 0; j < RY; j++) {
-            if (zsh || ((yfull >> j) & 1u)) {  // uniform
+            if constexpr (SEG > 1) {
+                const bool full = zsh || ((yfull >> j) & 1u);  // per lane
+                if (__builtin_amdgcn_ballot_w64(full) != 0) {  // uniform, and rare: the first and last y tiles only
+                    const __amdgpu_buffer_rsrc_t r = rsrc_of(cube, z);
+#pragma unroll
+                    for (int i = 0; i < RX; i++) {
+                        const float4 t = buf_ld4(r, full ? goff[j][i] : OOB);
+                        q[j][i] = full ? t : select4(flags[j][i], q[j][i], sx[j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < RX; i++) q[j][i] = select4(flags[j][i], q[j][i], sx[j]);
+                }
+            } else if (zsh || ((yfull >> j) & 1u)) {  // uniform
                 const __amdgpu_buffer_rsrc_t r = rsrc_of(cube, z);
 #pragma unroll
                 for (int i = 0; i < RX; i++) q[j][i] = buf_ld4(r, goff[j][i]);
@@ -241,8 +261,16 @@ __global__ __launch_bounds__(NW * 64) void tb_spc_kernel(const TbParams p)
                 // a row (or plane) that is shell throughout is read from `even` in the first place: a choice between two
                 // descriptors, uniform over the wave, instead of a second load later
                 const bool whole = more && patch && (zshell(pz + 1) || ((yfull >> j) & 1u));
+                if constexpr (SEG > 1) {  // `whole` differs from lane to lane: both loads, each lane's offset in range for one of them
 #pragma unroll
-                for (int i = 0; i < RX; i++) nx[j][i] = buf_ld4(whole ? re : rn, goff[j][i]);
+                    for (int i = 0; i < RX; i++) {
+                        const float4 a = buf_ld4(rn, whole ? OOB : goff[j][i]), b = buf_ld4(re, whole ? goff[j][i] : OOB);
+                        nx[j][i] = whole ? b : a;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < RX; i++) nx[j][i] = buf_ld4(whole ? re : rn, goff[j][i]);
+                }
                 mvx[j] = buf_ld4(rm, shq[j]);
                 evx[j] = buf_ld4(re, shq[j]);
             }
@@ -326,13 +354,13 @@ __global__ __launch_bounds__(NW * 64) void tb_spc_kernel(const TbParams p)
     }
 }
 
-template <int NW, int RY, int RX, int GOLDEN>
+template <int NW, int RY, int RX, int GOLDEN, int SEG>
 void tbs_launch(const TbParams &p, dim3 grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((tb_spc_kernel<NW, RY, RX, GOLDEN>), grid, dim3(NW * 64), 0, s, p);
+    hipLaunchKernelGGL((tb_spc_kernel<NW, RY, RX, GOLDEN, SEG>), grid, dim3(NW * 64), 0, s, p);
 }
 
-template <int NW, int RY, int RX, int GOLDEN>
+template <int NW, int RY, int RX, int GOLDEN, int SEG = 1>
 struct TbsRegistrar {
     TbsRegistrar()
     {
@@ -346,10 +374,12 @@ struct TbsRegistrar {
         v.threads = NW * 64;
         v.lds_bytes = 2 * NW * 4 * RX * 64 * 16;
         v.shells = 1;
-        v.launch = &tbs_launch<NW, RY, RX, GOLDEN>;
+        v.seg = SEG;
+        v.launch = &tbs_launch<NW, RY, RX, GOLDEN, SEG>;
         register_tb_variant(v);
     }
 };
 #define FDTDX_TBS_VARIANT(NW, RY, RX, GOLDEN) static ::fdtdx::TbsRegistrar<NW, RY, RX, GOLDEN> tbsreg_##NW##_##RY##_##RX##_##GOLDEN;
+#define FDTDX_TBS_STRIP_VARIANT(NW, RY, GOLDEN, SEG) static ::fdtdx::TbsRegistrar<NW, RY, 1, GOLDEN, SEG> tbsstrip_##NW##_##RY##_##GOLDEN##_##SEG;
 
 }  // namespace fdtdx

@@ -112,6 +112,19 @@ def test_fused_strip_tail_radius2_and_host_order(oracle_cpu, shape, golden):
             assert "fused3" in info and "+strip tail" in info, info
 
 
+@pytest.mark.parametrize("golden", [False, True])
+@pytest.mark.parametrize("shape", [(9, 130, 1024), (12, 47, 513), (14, 75, 1036), (9, 12, 1024)])
+def test_fused_strip_tail_13_point(oracle_cpu, shape, golden):
+    """The 13-point two-step kernel's strip shape: a wave's four segments lie in four y tiles, so "this row is shell throughout" is
+    a per-lane fact there (first and last y tile, one-row-high grids included); in-place loop over two cubes, both orders."""
+    info = run(oracle_cpu, "spc13", shape, 7, tb_zchunks=2, golden=golden)
+    assert "fused2" in info and "+strip tail" in info, info
+    info = run(oracle_cpu, "spc13", shape, 6, golden=golden)
+    assert "fused2" in info and "+strip tail" in info, info
+    info = run(oracle_cpu, "spc13", shape, 7, no_strip=1, golden=golden)
+    assert "fused2" in info and "+half-width tail" in info, info
+
+
 @pytest.mark.parametrize("steps", [4, 5, 6, 7, 8, 9, 11])
 def test_fused_radius2_step_counts(oracle_cpu, steps):
     """fdtd2's update fused two steps per launch (tbm_kernel.h): several y tiles and z chunks, ragged x."""
