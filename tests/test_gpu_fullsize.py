@@ -344,3 +344,19 @@ def test_config5_per_gpu_size_spc13_in_place_fused_loop(oracle_cpu):
     del a, b
     torch.cuda.empty_cache()
     assert fused == single, info
+
+
+@pytest.mark.parametrize("M,shape", [(5, (420, 700, 800)), (8, (430, 700, 800))])
+def test_several_rounds_of_short_chunks(oracle_cpu, M, shape):
+    """Planes whose tiles fill the CUs badly in one round (176 or 154 tiles on 256 CUs) are swept in several rounds of shorter z
+    chunks, more workgroups than CUs: same bits as the oracle."""
+    a = np.random.default_rng(M).random(shape, dtype=np.float32)
+    b = np.random.default_rng(M + 100).random(shape, dtype=np.float32)
+    ca, cb = a.copy(), b.copy()
+    oracle_cpu.run("star", ca, cb, 2, M=M, order=oracle_cpu.ORDER_CHAIN)
+    ga, gb = gpu_run("star", M, a, b, 2)
+    gx, gy, gz = (int(v) for v in gpu_run.info.split("grid=")[1].split(" ")[0].split("x"))
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert gz > 1 and gx * gy * gz > 256, gpu_run.info
+    assert np.array_equal(ga.view(np.uint32), ca.view(np.uint32)), gpu_run.info
+    assert np.array_equal(gb.view(np.uint32), cb.view(np.uint32)), gpu_run.info
