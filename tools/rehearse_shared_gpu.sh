@@ -13,3 +13,5 @@ import json
 d=json.loads(open("gpurun_out/r03_reh_config3.json").read().strip().splitlines()[-1])
 print(d["value"], d["config"].get("exchange"), {k:v["gcells"] for k,v in d["variants"].items()})
 PY
+# (three or four ranks on the one GPU: export GPU_MAX_HW_QUEUES=2 first -- with four hardware queues per process the driver starts
+# time-slicing the GPU between the processes and every exchange waits for a scheduling quantum, 2.7 / 5.7 ms)
