@@ -3,6 +3,10 @@
 usage: python tools/tune.py [--kinds star,spc13,jacobi7] [--radii 1,2,..] [--n 512] [--steps 20]
 Prints one line per (kind, radius, variant, zchunks) with Gcell/s; inputs are the drivers'
 mt19937 fields (fdtd1.cu:21-31) generated once per radius.
+The sweeps run against the power limit, so their speed depends on the values in the cubes, and shapes rank differently on
+the normalised fields this tool sweeps by default (--bounded 1) than on the drivers' own first steps, which is what
+bench.py --steps 20 times: a shape that leads here by 7 % can be level there.  Take the decision from tools/shape_scan.sh /
+tools/lib_shape_scan.sh (bench.py per shape on the drivers' fields); use this tool to list the shapes and for a first ranking.
 """
 import argparse
 import json
