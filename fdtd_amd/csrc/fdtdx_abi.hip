@@ -478,9 +478,10 @@ static void default_shape(int kind, int r, int nq, int *tq, int *ly, int *ry, un
     switch (r) {
     case 5: *tq = 64, *ly = 16, *ry = 1; break;  // (launch_sweep prefers a 768-lane shape where its tiles fill the CUs)
     case 6: *tq = 32, *ly = 16, *ry = 2; break;  // 32 x 32 cells on 512 lanes: 2.5 % ahead of 64 x 16 in a time loop
-    case 7: *tq = 32, *ly = 32, *ry = 1; break;  // level with 32 x 16 in a lone sweep, 6 % ahead of it in a time loop (shell strips)
-    // radius 8: the same 32 x 32 tile on 512 lanes, every lane two adjacent rows, late publish (star_pairs_late in star_kernel.h):
-    // 1.3 % ahead of one row per lane on 1024 lanes over 100 steps of the drivers' fields (radius 7: 1.5 % behind)
+    // radius 7 and 8: 32 x 32 tiles on 512 lanes, every lane two adjacent rows, late publish (star_pairs_late in star_kernel.h).  Against one
+    // row per lane on 1024 lanes, on the drivers' fields: radius 8 +1.3 % over 100 steps; radius 7 +0.5 to +1.7 % over the first 20 steps on
+    // three boxes, -1.5 to +0.6 % over 100
+    case 7: *tq = 32, *ly = 16, *ry = 2; break;
     default: *tq = 32, *ly = 16, *ry = 2; break;
     }
 }
